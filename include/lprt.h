@@ -1,0 +1,308 @@
+/*
+ * lprt.h — C ABI of the MI355X-native low-precision path tracer (hot path only).
+ *
+ * This is the drop-in boundary for the rendering hot path of
+ * ioissss/Low-precision-raytracer (rt/trace + rt/rtrt). The reference has no
+ * FFI; its "operator surface" is C++ templates launched from
+ * rt/gui/imgui_window.cu:121-329. Every entry point below names the reference
+ * symbol it replaces (paths relative to the reference root).
+ *
+ * Conventions:
+ *   - matrices are row-major data[r][c] acting on column vectors
+ *     (rt/rtrt/memory.hpp:285-293);
+ *   - all scene inputs are float32 on the host; the device converts to the
+ *     context's DataT (float or packed half) exactly where the reference
+ *     converts (float16(float), round-to-nearest-even);
+ *   - every function returns LPRT_OK (0) or a negative error code; the text of
+ *     the last error is available through lprt_last_error(); no exceptions
+ *     cross this boundary (reference: RT_CHECK_CUDA throws,
+ *     rt/utils/cu_exception.cu:9-13);
+ *   - one context per device; calls on one context must be serialised by the
+ *     caller (reference: single GL thread, default stream).
+ */
+#ifndef LPRT_H
+#define LPRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LPRT_MAX_DIRECT_LIGHT 4u /* rt/gui/imgui_window.cu:81 */
+#define LPRT_MAX_BOUNCES 2u      /* rt/gui/imgui_window.cu:356 */
+
+enum {
+    LPRT_OK = 0,
+    LPRT_ERR_INVALID = -1,   /* bad argument / bad state */
+    LPRT_ERR_DEVICE = -2,    /* HIP runtime error (text in lprt_last_error) */
+    LPRT_ERR_NO_DEVICE = -3, /* no usable GPU: there is no CPU fallback */
+    LPRT_ERR_LIMIT = -4      /* a documented capacity limit was exceeded */
+};
+
+typedef enum { LPRT_F32 = 0, LPRT_F16 = 1 } lprt_precision; /* DataT, rt/gui/imgui_window.cu:78-80 */
+
+/* RDVertex<float>, rt/rtrt/memory.hpp:26-41 (packed, 64 B). */
+typedef struct {
+    float position[3];
+    float normal[3];
+    float tangent[3];
+    float color[3];
+    float uv0[2];
+    float uv1[2];
+} lprt_vertex;
+
+/* CUDAMeshVAO, rt/rtrt/memory.hpp:560-566: one glTF primitive = one BLAS. */
+typedef struct {
+    uint32_t ebo_index; /* must be 0: the loader builds one shared EBO (rt/rtrt/loader.cu:797-802) */
+    uint32_t vbo_index; /* must be 0 */
+    uint32_t ebo_offset;
+    uint32_t ebo_length;
+} lprt_mesh_vao;
+
+/* CUDAMaterial<float>, rt/rtrt/memory.hpp:303-332 (only the fields shade() reads). */
+typedef struct {
+    float color[3];
+    float emission[3];
+    float metallic;
+    float roughness;
+    uint32_t double_sided;
+    uint32_t uv_color;  /* 0/1: sample tex_color with uv0/uv1; >=2: no texture (rt/rtrt/cuda.hpp:1851) */
+    uint32_t tex_color; /* handle from lprt_upload_texture, ignored when uv_color >= 2 */
+    uint32_t reserved;
+} lprt_material;
+
+/* CUDAObjectConstantData<float>, rt/rtrt/memory.hpp:279-301. */
+typedef struct {
+    float transform_L2W[16];
+    float transform_W2L[16];
+    uint32_t materialid;
+    uint32_t objectid; /* VAO index */
+} lprt_object;
+
+/* world-space AABB of one object, RDScene::objects_aabb, rt/rtrt/memory.hpp:699. */
+typedef struct {
+    float lower[3];
+    float upper[3];
+} lprt_aabb;
+
+/* RDLight<float>, rt/rtrt/memory.hpp:43-51. */
+enum { LPRT_LIGHT_SPOT = 0, LPRT_LIGHT_POINT = 1, LPRT_LIGHT_DIRECTIONAL = 2 };
+typedef struct {
+    uint32_t type;
+    float inner_cone_angle;
+    float outer_cone_angle;
+    float maximum_distance;
+    float direction[3];
+    float intensity[3];
+    float position[3];
+} lprt_light;
+
+/* RDCamera<float>, rt/rtrt/memory.hpp:382-405. */
+typedef struct {
+    float transform[16];     /* world -> view */
+    float transform_L2W[16]; /* camera local -> world */
+    float field_of_view_y;
+    float aspect_ratio;
+    float z_near;
+    float z_far;
+} lprt_camera;
+
+/* RDSkybox<float>::Ref, rt/rtrt/memory.hpp:664-690. */
+typedef struct {
+    uint32_t valid;
+    uint32_t texture; /* handle from lprt_upload_texture */
+    float delta_x;
+    float delta_y;
+    float exposure;
+} lprt_skybox;
+
+/* Renderer::Settings + DemoSetting, rt/gui/imgui_window.cu:94-100, rt/rtrt/cuda.hpp:2161-2168.
+ * spp is a build-side extension; spp = 1 is one reference frame. */
+typedef struct {
+    uint32_t spp;
+    uint32_t gi_on;
+    uint32_t svgf;
+    uint32_t add_direct_out;
+    uint32_t add_gi_colored;
+    uint32_t add_gi_white;
+    uint32_t demodulate;
+    float svgf_color_mix_weight;
+    float svgf_moments_mix_weight;
+    float taa_mix_weight;
+    /* 3*spp seeds (A_s: temporal map / B_s: shade #1 / C_s: shade #2), replacing the
+     * reference's three rand() calls per frame (rt/gui/imgui_window.cu:145,159,199).
+     * NULL: derived from the frame counter as A = 3(f*spp+s)+1, B = A+1, C = A+2. */
+    const uint64_t *seeds;
+    uint32_t rebuild_blas; /* rebuild every BLAS on the GPU before the frame (config C4) */
+    uint32_t reserved;
+} lprt_frame_settings;
+
+/* Ray / hit records for lprt_trace_rays (Ray, Intersection, SkipGeometry: rt/rtrt/cuda.hpp:38-57,187-190). */
+typedef struct {
+    float source[3];
+    float direction[3];
+    float min_distance;
+    float max_distance;    /* use 1e5f for "no limit", as the reference does (cuda.hpp:624) */
+    uint32_t skip_vao;     /* UINT32_MAX: skip nothing */
+    uint32_t skip_inobject_offset;
+} lprt_ray;
+
+typedef struct {
+    uint32_t hit; /* 0 = Intersection::NONE */
+    uint32_t inscene_objid;
+    uint32_t inobject_offset;
+    float t;
+    float barycentric[3];
+} lprt_hit;
+
+/* Work counters for the roofline's algorithmic bytes. */
+typedef struct {
+    uint64_t rays;
+    uint64_t tlas_node_visits; /* distinct TLAS nodes whose box was tested */
+    uint64_t aabbw_tests;      /* per-object world-box tests at TLAS leaves */
+    uint64_t object_visits;    /* BLAS traversals entered */
+    uint64_t blas_node_visits; /* distinct BLAS nodes whose box was tested */
+    uint64_t tri_tests;
+    uint64_t fallback_tests;   /* fp32 edge-zone re-tests (cuda.hpp:267-328) */
+} lprt_counters;
+
+typedef enum {
+    /* RTRTProcedureBuffer planes (rt/rtrt/cuda.hpp:1475-1634); all read back as float32 */
+    LPRT_BUF_COLOR_INPROGRESS = 0, /* [rows][W][3] */
+    LPRT_BUF_MUL_GI_COLORED = 1,   /* [rows][W][3] (after SVGF when svgf=1) */
+    LPRT_BUF_MUL_GI_WHITE = 2,     /* [rows][W][3] */
+    LPRT_BUF_INTENSITY0 = 3,       /* [rows][W][3] */
+    LPRT_BUF_INTENSITY1 = 4,       /* [rows][W][3] */
+    LPRT_BUF_ALBEDO = 5,           /* [rows][W][3] */
+    LPRT_BUF_OUTPUT = 6,           /* [rows][W][4] RGBA32F display surface (cuda.hpp:2441-2455) */
+    /* G-buffer planes (rt/rtrt/cuda.hpp:950-1012) */
+    LPRT_BUF_G_POSITION = 7,       /* [rows][W][4] */
+    LPRT_BUF_G_NORMAL_DEPTH = 8,   /* [rows][W][4] */
+    LPRT_BUF_G_TANGENT = 9,        /* [rows][W][4] */
+    LPRT_BUF_G_UV0UV1 = 10,        /* [rows][W][4] */
+    LPRT_BUF_G_COLOR = 11,         /* [rows][W][4] RGBA8 widened to float 0..255 */
+    LPRT_BUF_G_OBJID = 12,         /* [rows][W][1] exact integers as float */
+    LPRT_BUF_G_OFFSET = 13,        /* [rows][W][1] */
+    /* pre-denoise split lobes (averaged over spp), for SVGF input parity */
+    LPRT_BUF_RAW_GI_COLORED = 14,  /* [rows][W][3] */
+    LPRT_BUF_RAW_GI_WHITE = 15,    /* [rows][W][3] */
+    LPRT_BUF_RAW_COLOR = 16,       /* [rows][W][3] color_inprogress before add_denoised_color */
+    LPRT_BUF_COUNT = 17
+} lprt_buffer_id;
+
+/* Per-stage GPU time of the last frame(s); labels follow the reference's GUI timer
+ * (rt/gui/imgui_window.cu:154-280). */
+typedef enum {
+    LPRT_STAGE_BUILD_BLAS = 0,
+    LPRT_STAGE_BUILD_TLAS = 1,
+    LPRT_STAGE_PRIMARY = 2,
+    LPRT_STAGE_TEMPORAL_MAP = 3,
+    LPRT_STAGE_RNG = 4,
+    LPRT_STAGE_SHADE1 = 5,
+    LPRT_STAGE_TRACE_DI1 = 6,
+    LPRT_STAGE_TRACE_GI = 7,
+    LPRT_STAGE_SHADE2 = 8,
+    LPRT_STAGE_TRACE_DI2 = 9,
+    LPRT_STAGE_COMPOSE = 10,
+    LPRT_STAGE_SVGF = 11,
+    LPRT_STAGE_TAA_OUTPUT = 12,
+    LPRT_STAGE_BACKUP = 13,
+    LPRT_STAGE_COUNT = 14
+} lprt_stage_id;
+
+typedef struct lprt_ctx lprt_ctx;
+
+/* ---- lifetime ------------------------------------------------------------------------- */
+
+/* Replaces Renderer<DataT>::Renderer(width, height, n_vaos) (rt/gui/imgui_window.cu:349-357):
+ * allocates every per-pixel buffer of RTRTProcedureBuffer<DataT,4> + GBuffer + output surface
+ * for image rows [row_begin, row_end) of a width x height frame (row_begin = 0, row_end =
+ * height on one GPU; a row strip plus halo when frames are sharded). */
+int lprt_create(lprt_ctx **out, int device, uint32_t width, uint32_t height, uint32_t row_begin,
+                uint32_t row_end, lprt_precision precision);
+void lprt_destroy(lprt_ctx *ctx);
+const char *lprt_last_error(const lprt_ctx *ctx); /* ctx may be NULL: last create() error */
+
+/* All work is enqueued on this hipStream_t (default: a stream owned by the context). */
+int lprt_set_stream(lprt_ctx *ctx, void *hip_stream);
+int lprt_synchronize(lprt_ctx *ctx);
+
+/* ---- resources (loader side of the boundary) -------------------------------------------- */
+
+/* Replaces RDResource<DataT>::{objects_vbo, objects_ebo, objects_vao, compute_m}
+ * (rt/rtrt/memory.hpp:568-648, rt/rtrt/loader.cu:774-811) and
+ * CUDARenderGIData::fill_objects_cuda_vao (rt/rtrt/cuda.hpp:758-764).
+ * The device derives the DataT vertex copy, M_shift, M_shift_f32 and position_f32. */
+int lprt_upload_geometry(lprt_ctx *ctx, const lprt_vertex *vbo, uint32_t n_vertices,
+                         const uint32_t *ebo, uint32_t n_indices, const lprt_mesh_vao *vaos,
+                         uint32_t n_vaos);
+
+/* Replaces RDResource::materials + CUDARenderGIData::refresh_materials (rt/rtrt/cuda.hpp:749-755). */
+int lprt_upload_materials(lprt_ctx *ctx, const lprt_material *materials, uint32_t n_materials);
+
+/* Replaces RDTexture(data, w, h, sRGB) (rt/rtrt/memory.hpp:334-369): RGBA8, bilinear, wrap. */
+int lprt_upload_texture(lprt_ctx *ctx, const uint8_t *rgba8, uint32_t width, uint32_t height,
+                        uint32_t srgb, uint32_t *out_handle);
+
+/* Replaces ObjectBVH<DataT>(positions, indices) for every primitive (rt/trace/object_bvh.hpp:49-63,
+ * called at rt/rtrt/loader.cu:434) + fill_objects_bvh (rt/rtrt/cuda.hpp:767-773): GPU build
+ * (Morton codes, LSD radix sort, implicit median hierarchy, bottom-up refit). */
+int lprt_build_blas(lprt_ctx *ctx);
+
+/* ---- per-frame scene (scene-manager side of the boundary) --------------------------------- */
+
+/* Replaces RDScene<DataT> hand-over + CUDARenderGIData::get_render_input
+ * (rt/rtrt/cuda.hpp:662-710): uploads objects/lights/camera and rebuilds the TLAS on the GPU
+ * (SceneBVH::update, rt/trace/scene_bvh.hpp:50-70). transform_W2C is
+ * render_data->transform_W2C (rt/gui/imgui_window.cu:293-294), used only for reprojection. */
+int lprt_set_scene(lprt_ctx *ctx, const lprt_object *objects, const lprt_aabb *aabbs,
+                   uint32_t n_objects, const lprt_light *lights, uint32_t n_lights,
+                   const lprt_camera *camera, const float transform_W2C[16],
+                   const lprt_skybox *skybox);
+
+/* Replaces Renderer::render = render_gbuffer (traced primary rays, rt/rtrt/cuda.hpp:854-872)
+ * + render_cuda (rt/gui/imgui_window.cu:121-283). Asynchronous on the context's stream. */
+int lprt_render_frame(lprt_ctx *ctx, const lprt_frame_settings *settings);
+
+/* Drops temporal history (frame counter back to 0): the state right after Renderer construction. */
+int lprt_reset_history(lprt_ctx *ctx);
+
+/* ---- results ------------------------------------------------------------------------------ */
+
+/* Synchronises, converts to float32 and copies rows [row_begin,row_end) of one buffer. */
+int lprt_read_buffer(lprt_ctx *ctx, lprt_buffer_id id, float *dst, size_t n_floats);
+
+/* Device pointer to the RGBA32F output rows (tex_draw_target, rt/gui/imgui_window.cu:351):
+ * [row_end-row_begin][width][4] floats, valid until lprt_destroy. */
+int lprt_output_device_ptr(lprt_ctx *ctx, void **ptr, size_t *bytes);
+
+/* cast_ray<find_any,false> over a host ray batch (rt/rtrt/cuda.hpp:622-631), for hit-record parity
+ * and ray-rate measurement; rays are rounded to DataT on the device like a TraceGICommand. */
+int lprt_trace_rays(lprt_ctx *ctx, const lprt_ray *rays, uint32_t n_rays, int find_any,
+                    lprt_hit *hits);
+
+/* Counters are collected only while enabled (instrumented kernel variants). */
+int lprt_enable_counters(lprt_ctx *ctx, int enable);
+int lprt_get_counters(lprt_ctx *ctx, lprt_counters *out);
+int lprt_reset_counters(lprt_ctx *ctx);
+
+/* Per-stage HIP-event timing (ms, accumulated since the last reset) and launch counts. */
+int lprt_enable_stage_timing(lprt_ctx *ctx, int enable);
+int lprt_get_stage_times(lprt_ctx *ctx, float ms[LPRT_STAGE_COUNT], uint32_t launches[LPRT_STAGE_COUNT]);
+int lprt_reset_stage_times(lprt_ctx *ctx);
+
+/* Acceleration-structure read-back for parity tests against the oracle's traversal:
+ * sizes first (nodes == NULL), then data. Layout documented in DESIGN.md. */
+int lprt_get_blas_info(lprt_ctx *ctx, uint32_t vao_index, uint32_t *n_triangles, uint32_t *n_nodes,
+                       uint32_t *depth);
+int lprt_read_blas_order(lprt_ctx *ctx, uint32_t vao_index, uint32_t *tri_order, uint32_t n);
+int lprt_read_blas_boxes(lprt_ctx *ctx, uint32_t vao_index, float *boxes6, uint32_t n_nodes);
+
+const char *lprt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LPRT_H */
