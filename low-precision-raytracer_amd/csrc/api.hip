@@ -1,0 +1,715 @@
+// C-ABI entry points (include/lprt.h) over the templated renderer implementation.
+#include "build.hpp"
+#include "kernels.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+
+namespace lprt {
+
+struct CtxBase {
+    std::string error;
+    int device = 0;
+    Window win{};
+    lprt_precision precision = LPRT_F32;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    virtual ~CtxBase() {}
+    virtual void upload_geometry(const lprt_vertex *, uint32_t, const uint32_t *, uint32_t, const lprt_mesh_vao *, uint32_t) = 0;
+    virtual void upload_materials(const lprt_material *, uint32_t) = 0;
+    virtual void build_blas() = 0;
+    virtual void set_scene(const lprt_object *, const lprt_aabb *, uint32_t, const lprt_light *, uint32_t, const lprt_camera *,
+                           const float *, const lprt_skybox *) = 0;
+    virtual void trace_rays(const lprt_ray *, uint32_t, int, lprt_hit *) = 0;
+    virtual void get_counters(lprt_counters *) = 0;
+    virtual void reset_counters() = 0;
+    virtual void blas_info(uint32_t, uint32_t *, uint32_t *, uint32_t *) = 0;
+    virtual void read_blas_order(uint32_t, uint32_t *, uint32_t) = 0;
+    virtual void read_blas_boxes(uint32_t, float *, uint32_t) = 0;
+    virtual void render_frame(const lprt_frame_settings &) = 0;
+    virtual void reset_history() = 0;
+    virtual void read_buffer(lprt_buffer_id, float *, size_t) = 0;
+    virtual void output_ptr(void **, size_t *) = 0;
+    bool counters_enabled = false;
+    StageTimer timer;
+    uint64_t frame_index = 0;
+
+    // per-stage HIP events on the context's stream (only when enabled: they serialise nothing but cost a few us)
+    hipEvent_t get_event() {
+        hipEvent_t e;
+        if (!timer.pool.empty()) {
+            e = timer.pool.back();
+            timer.pool.pop_back();
+        } else {
+            LPRT_HIP(hipEventCreate(&e));
+        }
+        return e;
+    }
+    bool debug_sync = std::getenv("LPRT_DEBUG_SYNC") != nullptr;
+    template <typename F> void stage(int id, F &&f) {
+        if (!timer.enabled && !debug_sync) {
+            f();
+            return;
+        }
+        if (debug_sync) {
+            f();
+            hipError_t e = hipStreamSynchronize(stream);
+            if (e != hipSuccess)
+                throw std::string("stage ") + std::to_string(id) + " failed: " + hipGetErrorString(e);
+            std::fprintf(stderr, "[lprt] stage %d ok\n", id);
+            return;
+        }
+        hipEvent_t a = get_event(), b = get_event();
+        LPRT_HIP(hipEventRecord(a, stream));
+        f();
+        LPRT_HIP(hipEventRecord(b, stream));
+        timer.pending.push_back({id, a, b});
+        timer.launches[id]++;
+    }
+    void collect_times() {
+        for (auto &p : timer.pending) {
+            LPRT_HIP(hipEventSynchronize(p.b));
+            float ms = 0;
+            LPRT_HIP(hipEventElapsedTime(&ms, p.a, p.b));
+            timer.ms[p.stage] += ms;
+            timer.pool.push_back(p.a);
+            timer.pool.push_back(p.b);
+        }
+        timer.pending.clear();
+    }
+};
+
+template <typename T> struct Impl : CtxBase {
+    GeometryStore<T> geo;
+    TlasStore<T> tlas;
+    DevBuf d_materials32, d_materials, d_objects32, d_objects, d_lights32, d_lights, d_counters, d_rays, d_hits;
+    uint32_t n_materials = 0, n_objects = 0, n_lights = 0;
+    lprt_camera camera{};
+    lprt_skybox skybox{};
+    float w2c[16] = {};
+    bool have_scene = false;
+
+    // RTRTProcedureBuffer + GBuffer + SVGFBuffer x2 + output surface, one arena
+    DevBuf arena, d_readback, d_last_L2W;
+    FrameDev<T> fb{};
+    V4<T> *taa_a = nullptr, *taa_b = nullptr;
+    RngStore rng;
+    size_t arena_bytes = 0;
+    bool svgf_ran = false;
+
+    DevBuf d_debug;
+    Impl() {
+        d_counters.reserve(sizeof(Counters));
+        d_debug.reserve(64);
+        LPRT_HIP(hipMemset(d_debug.ptr, 0, 64));
+    }
+    // LPRT_BOUNDS builds: report the first failed index check
+    void check_debug() {
+        uint32_t dbg[4] = {0, 0, 0, 0};
+        LPRT_HIP(hipMemcpy(dbg, d_debug.ptr, sizeof(dbg), hipMemcpyDeviceToHost));
+        if (dbg[0]) {
+            LPRT_HIP(hipMemset(d_debug.ptr, 0, 64));
+            throw std::string("device bounds check ") + std::to_string(dbg[0]) + " failed: " + std::to_string(dbg[1]) + " vs " + std::to_string(dbg[2]);
+        }
+    }
+    template <typename U> U *carve(size_t &off, size_t count) {
+        off = (off + 255) & ~size_t(255);
+        U *p = reinterpret_cast<U *>(static_cast<char *>(arena.ptr) + off);
+        off += sizeof(U) * count;
+        return p;
+    }
+    void layout(bool dry, size_t &off) {
+        const size_t n = win.npix();
+        off = 0;
+        (void)dry;
+        fb.win = win;
+        fb.g_position = carve<V4<T>>(off, n);
+        fb.g_normal_depth = carve<V4<T>>(off, n);
+        fb.g_tangent = carve<V4<T>>(off, n);
+        fb.g_uv = carve<V4<T>>(off, n);
+        fb.g_color = carve<uint32_t>(off, n);
+        fb.g_objid = carve<uint32_t>(off, n);
+        fb.g_offset = carve<uint32_t>(off, n);
+        fb.gi_multiplier = carve<V4<T>>(off, n);
+        fb.gi_multiplier1 = carve<V4<T>>(off, n);
+        fb.intensity0 = carve<V4<T>>(off, n);
+        fb.intensity1 = carve<V4<T>>(off, n);
+        fb.view_direction = carve<V4<T>>(off, n);
+        fb.skips = carve<uint2>(off, n);
+        fb.gi_source = nullptr;
+        fb.gi_direction = carve<V4<T>>(off, n);
+        fb.gi_valid = carve<uint8_t>(off, n);
+        fb.lc_dir_maxt = carve<V4<T>>(off, n * LPRT_MAX_DIRECT_LIGHT);
+        fb.lc_multiplier = carve<V4<T>>(off, n * LPRT_MAX_DIRECT_LIGHT);
+        fb.lc_mask = carve<uint8_t>(off, n);
+        fb.sc_position = carve<V4<T>>(off, n);
+        fb.sc_normal = carve<V4<T>>(off, n);
+        fb.sc_tangent = carve<V4<T>>(off, n);
+        fb.sc_color = carve<V4<T>>(off, n);
+        fb.sc_uv = carve<V4<T>>(off, n);
+        fb.sc_type = carve<uint32_t>(off, n);
+        fb.sc_materialid = carve<uint32_t>(off, n);
+        fb.sc_objid = carve<uint32_t>(off, n);
+        fb.sc_offset = carve<uint32_t>(off, n);
+        fb.albedo = carve<V4<T>>(off, n);
+        fb.color_inprogress = carve<V4<T>>(off, n);
+        taa_a = carve<V4<T>>(off, n);
+        taa_b = carve<V4<T>>(off, n);
+        fb.taa_history = taa_a;
+        fb.acc_color = carve<float4>(off, n);
+        fb.acc_gi_colored = carve<float4>(off, n);
+        fb.acc_gi_white = carve<float4>(off, n);
+        fb.raw_color = carve<V4<T>>(off, n);
+        fb.raw_gi_colored = carve<V4<T>>(off, n);
+        fb.raw_gi_white = carve<V4<T>>(off, n);
+        for (int l = 0; l < 2; l++) {
+            fb.lobe[l].cv_a = carve<V4<T>>(off, n);
+            fb.lobe[l].cv_b = carve<V4<T>>(off, n);
+            fb.lobe[l].cv_c = carve<V4<T>>(off, n);
+            fb.lobe[l].illum = carve<T>(off, n);
+            fb.lobe[l].miu1_hist = carve<T>(off, n);
+            fb.lobe[l].miu2_hist = carve<T>(off, n);
+            fb.lobe[l].miu1_cur = carve<T>(off, n);
+            fb.lobe[l].miu2_cur = carve<T>(off, n);
+        }
+        fb.depth_gradient = carve<V2<T>>(off, n);
+        fb.svgf_map = carve<TemporalMapT<T>>(off, n);
+        fb.taa_map = carve<TemporalMapT<T>>(off, n);
+        fb.valid_frame_count = carve<uint8_t>(off, n);
+        fb.prev_frame_count = carve<uint8_t>(off, n);
+        fb.last_frame_id = carve<uint2>(off, n);
+        fb.output = carve<float4>(off, n);
+        fb.rng_state = carve<uint32_t>(off, 5 * n);
+        off = (off + 255) & ~size_t(255);
+    }
+    void ensure_frame_buffers() {
+        if (arena.ptr)
+            return;
+        size_t total = 0;
+        layout(true, total); // pointers relative to a null arena: sizes only
+        arena.reserve(total);
+        arena_bytes = total;
+        layout(false, total);
+        LPRT_HIP(hipMemsetAsync(arena.ptr, 0, arena_bytes, stream)); // thrust::device_vector zero-initialises (cuda.hpp:1599-1608)
+        rng.init(stream);
+    }
+    void ensure_last_L2W() {
+        size_t need = sizeof(M4<T>) * (size_t)std::max(geo.n_vaos, 1u);
+        if (d_last_L2W.bytes < need) {
+            d_last_L2W.reserve(need);
+            LPRT_HIP(hipMemsetAsync(d_last_L2W.ptr, 0, need, stream));
+        }
+        fb.last_frame_L2W = d_last_L2W.as<M4<T>>();
+    }
+    void reset_history() override {
+        frame_index = 0;
+        if (arena.ptr)
+            LPRT_HIP(hipMemsetAsync(arena.ptr, 0, arena_bytes, stream));
+    }
+    void render_frame(const lprt_frame_settings &fs) override {
+        require_ready();
+        ensure_frame_buffers();
+        ensure_last_L2W();
+        const uint32_t spp = fs.spp ? fs.spp : 1;
+        if (fs.rebuild_blas)
+            stage(LPRT_STAGE_BUILD_BLAS, [&] { geo.build_blas(stream); });
+        SceneDev<T> sc = scene_dev();
+        // camera + reprojection matrices in DataT (RDCamera<DataT>, transform_W2C)
+        for (int k = 0; k < 16; k++)
+            sc.cam_L2W.m[k] = (T)camera.transform_L2W[k];
+        sc.cam_fovy = (T)camera.field_of_view_y;
+        sc.sky_valid = 0;
+        Counters *cnt = counters_enabled ? d_counters.as<Counters>() : nullptr;
+        const uint32_t total_px = win.W * win.H, first_px = win.row_begin * win.W, npix = win.npix();
+        auto seed_of = [&](uint32_t s, int which) -> uint64_t {
+            if (fs.seeds)
+                return fs.seeds[3 * s + (uint32_t)which];
+            return 3 * (frame_index * spp + s) + 1 + (uint64_t)which;
+        };
+        stage(LPRT_STAGE_PRIMARY, [&] { launch_fill_gbuffer<T>(stream, sc, fb, cnt); });
+        const bool first = frame_index == 0;
+        uint32_t d_a = 0;
+        if (!first)
+            stage(LPRT_STAGE_RNG, [&] { d_a = rng.generate(stream, seed_of(0, 0), total_px, first_px, npix, fb.rng_state); });
+        stage(LPRT_STAGE_TEMPORAL_MAP, [&] { launch_temporal_map<T>(stream, sc, fb, first, d_a); });
+        for (uint32_t s = 0; s < spp; s++) {
+            uint32_t d_b = 0;
+            if (fs.gi_on)
+                stage(LPRT_STAGE_RNG, [&] { d_b = rng.generate(stream, seed_of(s, 1), total_px, first_px, npix, fb.rng_state); });
+            stage(LPRT_STAGE_SHADE1, [&] { launch_shade<T>(stream, sc, fb, true, !fs.gi_on, d_b); });
+            stage(LPRT_STAGE_TRACE_DI1, [&] { launch_trace_di<T>(stream, sc, fb, true, cnt); });
+            if (fs.gi_on) {
+                stage(LPRT_STAGE_TRACE_GI, [&] { launch_trace_gi<T>(stream, sc, fb, cnt); });
+                stage(LPRT_STAGE_SHADE2, [&] { launch_shade<T>(stream, sc, fb, false, true, 0u); });
+                stage(LPRT_STAGE_TRACE_DI2, [&] { launch_trace_di<T>(stream, sc, fb, false, cnt); });
+            }
+            stage(LPRT_STAGE_COMPOSE, [&] { launch_compose<T>(stream, fb, fs.gi_on != 0, fs.add_direct_out != 0, s, spp); });
+        }
+        const V4<T> *res0 = fb.lobe[0].cv_a, *res1 = fb.lobe[1].cv_a;
+        svgf_ran = fs.svgf != 0;
+        if (fs.svgf) {
+            stage(LPRT_STAGE_SVGF, [&] { launch_svgf<T>(stream, fb, fs.svgf_color_mix_weight, fs.svgf_moments_mix_weight); });
+            res0 = fb.lobe[0].cv_c;
+            res1 = fb.lobe[1].cv_c;
+        }
+        V4<T> *taa_next = (fb.taa_history == taa_a) ? taa_b : taa_a;
+        // last_frame_transform_W2C as used by THIS frame's temporal map was set at the end of the previous frame
+        stage(LPRT_STAGE_TAA_OUTPUT, [&] {
+            launch_finalize<T>(stream, sc, fb, res0, res1, taa_next, fs.add_gi_colored != 0, fs.add_gi_white != 0, fs.demodulate != 0,
+                               fs.taa_mix_weight, n_objects);
+        });
+        fb.taa_history = taa_next;
+        for (int k = 0; k < 16; k++)
+            fb.last_frame_W2C.m[k] = (T)w2c[k]; // buffer->last_frame_transform_W2C = render_data->transform_W2C (imgui_window.cu:277)
+        LPRT_HIP(hipGetLastError());
+        frame_index++;
+#if defined(LPRT_BOUNDS) || defined(LPRT_BOUNDS_A)
+        LPRT_HIP(hipStreamSynchronize(stream));
+        check_debug();
+#endif
+    }
+    void read_buffer(lprt_buffer_id id, float *dst, size_t n_floats) override {
+        ensure_frame_buffers();
+        const uint32_t n = win.npix();
+        int ch = 3;
+        const V4<T> *v4 = nullptr;
+        const uint32_t *u32 = nullptr;
+        bool rgba8 = false;
+        switch (id) {
+        case LPRT_BUF_COLOR_INPROGRESS: v4 = fb.color_inprogress; break;
+        case LPRT_BUF_MUL_GI_COLORED: v4 = svgf_ran ? fb.lobe[0].cv_c : fb.lobe[0].cv_a; break;
+        case LPRT_BUF_MUL_GI_WHITE: v4 = svgf_ran ? fb.lobe[1].cv_c : fb.lobe[1].cv_a; break;
+        case LPRT_BUF_INTENSITY0: v4 = fb.intensity0; break;
+        case LPRT_BUF_INTENSITY1: v4 = fb.intensity1; break;
+        case LPRT_BUF_ALBEDO: v4 = fb.albedo; break;
+        case LPRT_BUF_RAW_GI_COLORED: v4 = fb.raw_gi_colored; break;
+        case LPRT_BUF_RAW_GI_WHITE: v4 = fb.raw_gi_white; break;
+        case LPRT_BUF_RAW_COLOR: v4 = fb.raw_color; break;
+        case LPRT_BUF_G_POSITION: v4 = fb.g_position; ch = 4; break;
+        case LPRT_BUF_G_NORMAL_DEPTH: v4 = fb.g_normal_depth; ch = 4; break;
+        case LPRT_BUF_G_TANGENT: v4 = fb.g_tangent; ch = 4; break;
+        case LPRT_BUF_G_UV0UV1: v4 = fb.g_uv; ch = 4; break;
+        case LPRT_BUF_G_COLOR: u32 = fb.g_color; ch = 4; rgba8 = true; break;
+        case LPRT_BUF_G_OBJID: u32 = fb.g_objid; ch = 1; break;
+        case LPRT_BUF_G_OFFSET: u32 = fb.g_offset; ch = 1; break;
+        case LPRT_BUF_OUTPUT: ch = 4; break;
+        default: throw std::string("unknown buffer id");
+        }
+        if (n_floats != (size_t)n * ch)
+            throw std::string("read_buffer: size mismatch (expected rows*W*channels floats)");
+        if (id == LPRT_BUF_OUTPUT) {
+            LPRT_HIP(hipMemcpyAsync(dst, fb.output, sizeof(float) * n_floats, hipMemcpyDeviceToHost, stream));
+        } else {
+            d_readback.reserve(sizeof(float) * n_floats);
+            if (v4)
+                launch_read_v4<T>(stream, v4, d_readback.as<float>(), n, ch);
+            else
+                launch_read_u32(stream, u32, d_readback.as<float>(), n, rgba8);
+            LPRT_HIP(hipMemcpyAsync(dst, d_readback.ptr, sizeof(float) * n_floats, hipMemcpyDeviceToHost, stream));
+        }
+        LPRT_HIP(hipStreamSynchronize(stream));
+    }
+    void output_ptr(void **ptr, size_t *bytes) override {
+        ensure_frame_buffers();
+        *ptr = fb.output;
+        *bytes = sizeof(float4) * (size_t)win.npix();
+    }
+
+    void upload_geometry(const lprt_vertex *vbo, uint32_t nv, const uint32_t *ebo, uint32_t ni, const lprt_mesh_vao *vaos,
+                         uint32_t nvaos) override {
+        geo.upload(stream, vbo, nv, ebo, ni, vaos, nvaos);
+    }
+    void upload_materials(const lprt_material *m, uint32_t n) override {
+        n_materials = n;
+        d_materials32.reserve(sizeof(lprt_material) * (size_t)std::max(n, 1u));
+        d_materials.reserve(sizeof(MaterialT<T>) * (size_t)std::max(n, 1u));
+        if (n) {
+            LPRT_HIP(hipMemcpyAsync(d_materials32.ptr, m, sizeof(lprt_material) * (size_t)n, hipMemcpyHostToDevice, stream));
+            LPRT_HIP(hipStreamSynchronize(stream));
+            launch_convert_materials<T>(stream, d_materials32.as<lprt_material>(), d_materials.as<MaterialT<T>>(), n);
+        }
+    }
+    void build_blas() override { geo.build_blas(stream); }
+    void set_scene(const lprt_object *obj, const lprt_aabb *aabbs, uint32_t n, const lprt_light *lights, uint32_t nl,
+                   const lprt_camera *cam, const float *W2C, const lprt_skybox *sky) override {
+        n_objects = n;
+        n_lights = nl;
+        d_objects32.reserve(sizeof(lprt_object) * (size_t)std::max(n, 1u));
+        d_objects.reserve(sizeof(ObjConst<T>) * (size_t)std::max(n, 1u));
+        d_lights32.reserve(sizeof(lprt_light) * (size_t)std::max(nl, 1u));
+        d_lights.reserve(sizeof(LightT<T>) * (size_t)std::max(nl, 1u));
+        if (n)
+            LPRT_HIP(hipMemcpyAsync(d_objects32.ptr, obj, sizeof(lprt_object) * (size_t)n, hipMemcpyHostToDevice, stream));
+        if (nl)
+            LPRT_HIP(hipMemcpyAsync(d_lights32.ptr, lights, sizeof(lprt_light) * (size_t)nl, hipMemcpyHostToDevice, stream));
+        tlas.build(stream, aabbs, n);
+        LPRT_HIP(hipStreamSynchronize(stream)); // the caller's arrays may go away after return (pageable copies)
+        launch_convert_objects<T>(stream, d_objects32.as<lprt_object>(), d_objects.as<ObjConst<T>>(), n);
+        launch_convert_lights<T>(stream, d_lights32.as<lprt_light>(), d_lights.as<LightT<T>>(), nl);
+        camera = *cam;
+        std::memcpy(w2c, W2C, sizeof(w2c));
+        if (sky)
+            skybox = *sky;
+        else
+            skybox = lprt_skybox{};
+        have_scene = true;
+    }
+    SceneDev<T> scene_dev() const {
+        SceneDev<T> sc{};
+        sc.tlas_inner = tlas.d_inner.template as<InnerNode<T>>();
+        sc.tlas_leaf = tlas.d_leaf.template as<uint32_t>();
+        sc.tlas_root = tlas.d_root.template as<T>();
+        sc.tlas_slots = tlas.d_slots.template as<ObjSlot<T>>();
+        sc.tlas_depth = tlas.depth;
+        sc.n_objects = tlas.n_objects;
+        sc.objects = d_objects.template as<ObjConst<T>>();
+        sc.blas = geo.d_blas.template as<BlasInfo>();
+        sc.blas_roots = geo.d_roots.template as<T>();
+        sc.blas_inner = geo.d_inner.template as<InnerNode<T>>();
+        sc.blas_leaf = geo.d_leaf.template as<uint32_t>();
+        sc.tris = geo.d_tris.template as<TriRec<T>>();
+        sc.tris_f32 = geo.d_tris_f32.template as<TriRecF32>();
+        sc.vbo = geo.d_vbo.template as<Vertex<T>>();
+        sc.ebo = geo.d_ebo.template as<uint32_t>();
+        sc.vaos = geo.d_vaos.template as<lprt_mesh_vao>();
+        sc.materials = d_materials.template as<MaterialT<T>>();
+        sc.lights = d_lights.template as<LightT<T>>();
+        sc.textures = nullptr;
+        sc.n_lights = n_lights;
+        sc.n_vaos = geo.n_vaos;
+        sc.lim_vertices = geo.n_vertices;
+        sc.lim_indices = geo.n_indices;
+        sc.lim_tris = geo.n_tris;
+        sc.lim_inner = geo.n_inner;
+        sc.lim_leaves = geo.n_leaves;
+        sc.lim_objects = n_objects;
+        sc.lim_materials = n_materials;
+        sc.debug = d_debug.template as<uint32_t>();
+        return sc;
+    }
+    void require_ready() {
+        if (!geo.built)
+            throw std::string("BLAS not built: call lprt_build_blas after lprt_upload_geometry");
+        if (!have_scene)
+            throw std::string("no scene: call lprt_set_scene first");
+    }
+    void trace_rays(const lprt_ray *rays, uint32_t n, int find_any, lprt_hit *hits) override {
+        require_ready();
+        if (!n)
+            return;
+        d_rays.reserve(sizeof(lprt_ray) * (size_t)n);
+        d_hits.reserve(sizeof(lprt_hit) * (size_t)n);
+        LPRT_HIP(hipMemcpyAsync(d_rays.ptr, rays, sizeof(lprt_ray) * (size_t)n, hipMemcpyHostToDevice, stream));
+        launch_trace_rays<T>(stream, scene_dev(), d_rays.as<lprt_ray>(), n, find_any != 0, d_hits.as<lprt_hit>(),
+                             counters_enabled ? d_counters.as<Counters>() : nullptr);
+        LPRT_HIP(hipGetLastError());
+        LPRT_HIP(hipMemcpyAsync(hits, d_hits.ptr, sizeof(lprt_hit) * (size_t)n, hipMemcpyDeviceToHost, stream));
+        LPRT_HIP(hipStreamSynchronize(stream));
+    }
+    void get_counters(lprt_counters *out) override {
+        Counters c;
+        LPRT_HIP(hipMemcpyAsync(&c, d_counters.ptr, sizeof(c), hipMemcpyDeviceToHost, stream));
+        LPRT_HIP(hipStreamSynchronize(stream));
+        out->rays = c.rays;
+        out->tlas_node_visits = c.tlas_nodes;
+        out->aabbw_tests = c.aabbw;
+        out->object_visits = c.objects;
+        out->blas_node_visits = c.blas_nodes;
+        out->tri_tests = c.tris;
+        out->fallback_tests = c.fallbacks;
+    }
+    void reset_counters() override { LPRT_HIP(hipMemsetAsync(d_counters.ptr, 0, sizeof(Counters), stream)); }
+    void blas_info(uint32_t vao, uint32_t *n_tris, uint32_t *n_nodes, uint32_t *depth) override {
+        if (vao >= geo.n_vaos)
+            throw std::string("vao index out of range");
+        const BlasInfo &bi = geo.host_blas[vao];
+        *n_tris = bi.n_tris;
+        *depth = bi.depth;
+        *n_nodes = bi.n_tris ? (2u << bi.depth) - 1 : 0;
+    }
+    void read_blas_order(uint32_t vao, uint32_t *order, uint32_t n) override {
+        if (vao >= geo.n_vaos || !geo.built)
+            throw std::string("bad vao index or BLAS not built");
+        const BlasInfo &bi = geo.host_blas[vao];
+        if (n != bi.n_tris)
+            throw std::string("size mismatch");
+        if (!n)
+            return;
+        // sorted values are global triangle ids; report primitive-local triangle indices
+        LPRT_HIP(hipMemcpyAsync(order, geo.d_vals[geo.sorted_buf].template as<uint32_t>() + bi.tri_base, sizeof(uint32_t) * (size_t)n,
+                                hipMemcpyDeviceToHost, stream));
+        LPRT_HIP(hipStreamSynchronize(stream));
+        for (uint32_t i = 0; i < n; i++)
+            order[i] -= bi.tri_base;
+    }
+    // heap order: box[0] = root, box[i-1] = node i; each 6 floats (lo, hi)
+    void read_blas_boxes(uint32_t vao, float *boxes, uint32_t n_nodes) override {
+        if (vao >= geo.n_vaos || !geo.built)
+            throw std::string("bad vao index or BLAS not built");
+        const BlasInfo &bi = geo.host_blas[vao];
+        uint32_t expect = bi.n_tris ? (2u << bi.depth) - 1 : 0;
+        if (n_nodes != expect)
+            throw std::string("size mismatch");
+        if (!n_nodes)
+            return;
+        uint32_t n_inner = (1u << bi.depth) - 1;
+        std::vector<InnerNode<T>> inner(n_inner);
+        T root[6];
+        if (n_inner)
+            LPRT_HIP(hipMemcpyAsync(inner.data(), geo.d_inner.template as<InnerNode<T>>() + bi.inner_base, sizeof(InnerNode<T>) * n_inner,
+                                    hipMemcpyDeviceToHost, stream));
+        LPRT_HIP(hipMemcpyAsync(root, geo.d_roots.template as<T>() + 6 * bi.root_base, sizeof(root), hipMemcpyDeviceToHost, stream));
+        LPRT_HIP(hipStreamSynchronize(stream));
+        for (int k = 0; k < 6; k++)
+            boxes[k] = (float)root[k];
+        for (uint32_t i = 1; i <= n_inner; i++) {
+            const InnerNode<T> &nd = inner[i - 1];
+            float *c0 = boxes + 6 * (2 * i - 1), *c1 = boxes + 6 * (2 * i);
+            for (int k = 0; k < 3; k++) {
+                c0[k] = (float)nd.lo0[k];
+                c0[3 + k] = (float)nd.hi0[k];
+                c1[k] = (float)nd.lo1[k];
+                c1[3 + k] = (float)nd.hi1[k];
+            }
+        }
+    }
+};
+
+} // namespace lprt
+
+using namespace lprt;
+
+struct lprt_ctx {
+    std::unique_ptr<CtxBase> impl;
+};
+
+static thread_local std::string g_create_error;
+
+template <typename F> static int guarded(lprt_ctx *ctx, F &&f) {
+    if (!ctx || !ctx->impl)
+        return LPRT_ERR_INVALID;
+    CtxBase &c = *ctx->impl;
+    try {
+        (void)hipSetDevice(c.device);
+        f(c);
+        return LPRT_OK;
+    } catch (const HipError &e) {
+        char buf[512];
+        std::snprintf(buf, sizeof(buf), "%s failed: %s (%s:%d)", e.what, hipGetErrorString(e.code), e.file, e.line);
+        c.error = buf;
+        return LPRT_ERR_DEVICE;
+    } catch (const std::string &s) {
+        c.error = s;
+        return LPRT_ERR_INVALID;
+    } catch (const std::bad_alloc &) {
+        c.error = "host allocation failed";
+        return LPRT_ERR_DEVICE;
+    }
+}
+
+extern "C" {
+
+const char *lprt_version(void) { return "lprt-hip 0.1 (gfx950)"; }
+
+int lprt_create(lprt_ctx **out, int device, uint32_t width, uint32_t height, uint32_t row_begin, uint32_t row_end,
+                lprt_precision precision) {
+    if (!out)
+        return LPRT_ERR_INVALID;
+    *out = nullptr;
+    if (width == 0 || height == 0 || width > 65535 || height > 65535 || row_begin >= row_end || row_end > height ||
+        (precision != LPRT_F32 && precision != LPRT_F16)) {
+        g_create_error = "invalid size, row window or precision";
+        return LPRT_ERR_INVALID;
+    }
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0 || device < 0 || device >= n_dev) {
+        g_create_error = "no usable HIP device (this library has no CPU fallback)";
+        return LPRT_ERR_NO_DEVICE;
+    }
+    try {
+        LPRT_HIP(hipSetDevice(device));
+        std::unique_ptr<CtxBase> impl;
+        if (precision == LPRT_F32)
+            impl.reset(new Impl<float>());
+        else
+            impl.reset(new Impl<h16>());
+        impl->device = device;
+        impl->precision = precision;
+        impl->win = Window{width, height, row_begin, row_end};
+        LPRT_HIP(hipStreamCreateWithFlags(&impl->stream, hipStreamNonBlocking));
+        impl->own_stream = true;
+        auto *ctx = new lprt_ctx();
+        ctx->impl = std::move(impl);
+        ctx->impl->reset_counters();
+        *out = ctx;
+        return LPRT_OK;
+    } catch (const HipError &e) {
+        g_create_error = std::string(e.what) + " failed: " + hipGetErrorString(e.code);
+        return LPRT_ERR_DEVICE;
+    } catch (const std::string &s) {
+        g_create_error = s;
+        return LPRT_ERR_INVALID;
+    }
+}
+
+void lprt_destroy(lprt_ctx *ctx) {
+    if (!ctx)
+        return;
+    if (ctx->impl) {
+        (void)hipSetDevice(ctx->impl->device);
+        if (ctx->impl->stream)
+            (void)hipStreamSynchronize(ctx->impl->stream);
+        hipStream_t s = ctx->impl->own_stream ? ctx->impl->stream : nullptr;
+        ctx->impl.reset();
+        if (s)
+            (void)hipStreamDestroy(s);
+    }
+    delete ctx;
+}
+
+const char *lprt_last_error(const lprt_ctx *ctx) {
+    if (!ctx || !ctx->impl)
+        return g_create_error.c_str();
+    return ctx->impl->error.c_str();
+}
+
+int lprt_set_stream(lprt_ctx *ctx, void *hip_stream) {
+    return guarded(ctx, [&](CtxBase &c) {
+        LPRT_HIP(hipStreamSynchronize(c.stream));
+        if (c.own_stream)
+            (void)hipStreamDestroy(c.stream);
+        c.stream = static_cast<hipStream_t>(hip_stream);
+        c.own_stream = false;
+    });
+}
+int lprt_synchronize(lprt_ctx *ctx) {
+    return guarded(ctx, [&](CtxBase &c) { LPRT_HIP(hipStreamSynchronize(c.stream)); });
+}
+
+int lprt_upload_geometry(lprt_ctx *ctx, const lprt_vertex *vbo, uint32_t n_vertices, const uint32_t *ebo, uint32_t n_indices,
+                         const lprt_mesh_vao *vaos, uint32_t n_vaos) {
+    return guarded(ctx, [&](CtxBase &c) {
+        if ((n_vertices && !vbo) || (n_indices && !ebo) || (n_vaos && !vaos) || n_indices % 3)
+            throw std::string("null pointer or index count not a multiple of 3");
+        for (uint32_t i = 0; i < n_vaos; i++) {
+            if (vaos[i].ebo_index || vaos[i].vbo_index)
+                throw std::string("only one shared VBO/EBO is supported (ebo_index = vbo_index = 0)");
+            if (vaos[i].ebo_length % 3 || vaos[i].ebo_offset % 3 || (uint64_t)vaos[i].ebo_offset + vaos[i].ebo_length > n_indices)
+                throw std::string("primitive range outside the EBO or not whole triangles");
+            if (i && vaos[i].ebo_offset < vaos[i - 1].ebo_offset + vaos[i - 1].ebo_length)
+                throw std::string("primitives must be disjoint and ordered by ebo_offset");
+            if (vaos[i].ebo_length / 3 > (1u << 30))
+                throw std::string("primitive too large");
+        }
+        for (uint32_t i = 0; i < n_indices; i++)
+            if (ebo[i] >= n_vertices)
+                throw std::string("index out of range");
+        c.upload_geometry(vbo, n_vertices, ebo, n_indices, vaos, n_vaos);
+    });
+}
+int lprt_upload_materials(lprt_ctx *ctx, const lprt_material *materials, uint32_t n) {
+    return guarded(ctx, [&](CtxBase &c) {
+        if (n && !materials)
+            throw std::string("null materials");
+        c.upload_materials(materials, n);
+    });
+}
+int lprt_upload_texture(lprt_ctx *ctx, const uint8_t *, uint32_t, uint32_t, uint32_t, uint32_t *) {
+    return guarded(ctx, [&](CtxBase &) { throw std::string("textures are not implemented yet (SURVEY.md §8(f) rank 2)"); });
+}
+int lprt_build_blas(lprt_ctx *ctx) {
+    return guarded(ctx, [&](CtxBase &c) { c.build_blas(); });
+}
+int lprt_set_scene(lprt_ctx *ctx, const lprt_object *objects, const lprt_aabb *aabbs, uint32_t n_objects, const lprt_light *lights,
+                   uint32_t n_lights, const lprt_camera *camera, const float transform_W2C[16], const lprt_skybox *skybox) {
+    return guarded(ctx, [&](CtxBase &c) {
+        if ((n_objects && (!objects || !aabbs)) || (n_lights && !lights) || !camera || !transform_W2C)
+            throw std::string("null scene pointer");
+        if (n_objects > 1024)
+            throw std::string("more than 1024 object instances are not supported by the single-workgroup TLAS build");
+        c.set_scene(objects, aabbs, n_objects, lights, n_lights, camera, transform_W2C, skybox);
+    });
+}
+int lprt_trace_rays(lprt_ctx *ctx, const lprt_ray *rays, uint32_t n_rays, int find_any, lprt_hit *hits) {
+    return guarded(ctx, [&](CtxBase &c) {
+        if (n_rays && (!rays || !hits))
+            throw std::string("null ray/hit pointer");
+        c.trace_rays(rays, n_rays, find_any, hits);
+    });
+}
+int lprt_enable_counters(lprt_ctx *ctx, int enable) {
+    return guarded(ctx, [&](CtxBase &c) { c.counters_enabled = enable != 0; });
+}
+int lprt_get_counters(lprt_ctx *ctx, lprt_counters *out) {
+    return guarded(ctx, [&](CtxBase &c) { c.get_counters(out); });
+}
+int lprt_reset_counters(lprt_ctx *ctx) {
+    return guarded(ctx, [&](CtxBase &c) { c.reset_counters(); });
+}
+int lprt_get_blas_info(lprt_ctx *ctx, uint32_t vao, uint32_t *n_tris, uint32_t *n_nodes, uint32_t *depth) {
+    return guarded(ctx, [&](CtxBase &c) { c.blas_info(vao, n_tris, n_nodes, depth); });
+}
+int lprt_read_blas_order(lprt_ctx *ctx, uint32_t vao, uint32_t *order, uint32_t n) {
+    return guarded(ctx, [&](CtxBase &c) { c.read_blas_order(vao, order, n); });
+}
+int lprt_read_blas_boxes(lprt_ctx *ctx, uint32_t vao, float *boxes, uint32_t n_nodes) {
+    return guarded(ctx, [&](CtxBase &c) { c.read_blas_boxes(vao, boxes, n_nodes); });
+}
+
+} // extern "C"
+
+// ---- frame pipeline -------------------------------------------------------------------------------------
+extern "C" {
+int lprt_render_frame(lprt_ctx *ctx, const lprt_frame_settings *fs) {
+    return guarded(ctx, [&](CtxBase &c) {
+        if (!fs)
+            throw std::string("null settings");
+        if (fs->spp > 4096)
+            throw std::string("spp too large");
+        c.render_frame(*fs);
+    });
+}
+int lprt_reset_history(lprt_ctx *ctx) {
+    return guarded(ctx, [&](CtxBase &c) { c.reset_history(); });
+}
+int lprt_read_buffer(lprt_ctx *ctx, lprt_buffer_id id, float *dst, size_t n_floats) {
+    return guarded(ctx, [&](CtxBase &c) {
+        if (!dst)
+            throw std::string("null destination");
+        c.read_buffer(id, dst, n_floats);
+    });
+}
+int lprt_output_device_ptr(lprt_ctx *ctx, void **ptr, size_t *bytes) {
+    return guarded(ctx, [&](CtxBase &c) {
+        if (!ptr || !bytes)
+            throw std::string("null out pointer");
+        c.output_ptr(ptr, bytes);
+    });
+}
+int lprt_enable_stage_timing(lprt_ctx *ctx, int enable) {
+    return guarded(ctx, [&](CtxBase &c) { c.timer.enabled = enable != 0; });
+}
+int lprt_get_stage_times(lprt_ctx *ctx, float ms[LPRT_STAGE_COUNT], uint32_t launches[LPRT_STAGE_COUNT]) {
+    return guarded(ctx, [&](CtxBase &c) {
+        c.collect_times();
+        for (int i = 0; i < LPRT_STAGE_COUNT; i++) {
+            if (ms)
+                ms[i] = c.timer.ms[i];
+            if (launches)
+                launches[i] = c.timer.launches[i];
+        }
+    });
+}
+int lprt_reset_stage_times(lprt_ctx *ctx) {
+    return guarded(ctx, [&](CtxBase &c) {
+        c.collect_times();
+        for (int i = 0; i < LPRT_STAGE_COUNT; i++) {
+            c.timer.ms[i] = 0;
+            c.timer.launches[i] = 0;
+        }
+    });
+}
+}

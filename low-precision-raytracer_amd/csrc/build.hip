@@ -1,0 +1,675 @@
+// Geometry preparation (B3) and acceleration-structure construction on the GPU (B1, B2).
+//
+// B3 replaces RDResource::compute_m (rt/rtrt/memory.hpp:621-648): per-triangle inverse transform
+//    M_shift_f32 / M_shift and position_f32, computed on the device with the same
+//    DifferenceOfProducts cofactors (rt/math/matrix.hpp:407-427, 829-843).
+// B1 replaces ObjectBVH::build_object_bvh (rt/trace/object_bvh.hpp:49-134), a single-threaded CPU
+//    median split, by: Morton codes of triangle centroids -> own LSD radix sort (wave ballot ranking,
+//    no Thrust/rocPRIM) -> implicit perfect median tree over the sorted order -> bottom-up boxes.
+// B2 replaces SceneBVH::update (rt/trace/scene_bvh.hpp:50-133), rebuilt per frame on the CPU, by a
+//    single-workgroup kernel (LDS bitonic sort + the same tree).
+#include "build.hpp"
+
+namespace lprt {
+
+// ---- helpers ------------------------------------------------------------------------------------
+__device__ __forceinline__ int f32_ordered(float f) {
+    int i = __float_as_int(f);
+    return i ^ ((i >> 31) & 0x7fffffff);
+}
+__device__ __forceinline__ float f32_unordered(int i) { return __int_as_float(i ^ ((i >> 31) & 0x7fffffff)); }
+
+// round a float bound to DataT towards -inf / +inf so stored boxes always contain the f32 box (Q2)
+template <typename T> __device__ __forceinline__ T round_down(float f);
+template <typename T> __device__ __forceinline__ T round_up(float f);
+template <> __device__ __forceinline__ float round_down<float>(float f) { return f; }
+template <> __device__ __forceinline__ float round_up<float>(float f) { return f; }
+__device__ __forceinline__ h16 h16_step(h16 h, bool up) { // next representable half towards +inf (up) or -inf
+    unsigned short b = __builtin_bit_cast(unsigned short, h);
+    if ((b & 0x7fff) == 0)
+        b = up ? 0x0001 : 0x8001;
+    else if (((b & 0x8000) == 0) == up)
+        b = (unsigned short)(b + 1);
+    else
+        b = (unsigned short)(b - 1);
+    return __builtin_bit_cast(h16, b);
+}
+template <> __device__ __forceinline__ h16 round_down<h16>(float f) {
+    h16 h = (h16)f;
+    if ((float)h > f)
+        h = h16_step(h, false);
+    return h;
+}
+template <> __device__ __forceinline__ h16 round_up<h16>(float f) {
+    h16 h = (h16)f;
+    if ((float)h < f)
+        h = h16_step(h, true);
+    return h;
+}
+
+__device__ __forceinline__ float diff_of_products(float a, float b, float c, float d) { // matrix.hpp:829-834
+    float cd = c * d;
+    float err = __builtin_fmaf(-c, d, cd);
+    float dop = __builtin_fmaf(a, b, -cd);
+    return dop + err;
+}
+
+// ---- B3 -----------------------------------------------------------------------------------------
+template <typename T> __global__ void k_convert_vertices(const lprt_vertex *in, Vertex<T> *out, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const float *s = reinterpret_cast<const float *>(in + i);
+    T *d = reinterpret_cast<T *>(out + i);
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        d[k] = cvt<T>(s[k]); // float16(float), number.hpp:16
+}
+
+// one thread per triangle (global EBO order): M2 = inverse([v0-v2, v1-v2, cross(v0-v2,v1-v2) - v2])
+__global__ void k_tri_prepare(const lprt_vertex *vbo, const uint32_t *ebo, uint32_t n_tris, const uint32_t *tri_prim,
+                              TriRecF32 *mf32, float *tri_bounds, int *prim_cbounds) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = g < n_tris;
+    float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+    uint32_t p = 0xffffffffu;
+    if (valid) {
+        const float *p0 = vbo[ebo[3 * g + 0]].position;
+        const float *p1 = vbo[ebo[3 * g + 1]].position;
+        const float *p2 = vbo[ebo[3 * g + 2]].position;
+        float v0[3] = {p0[0], p0[1], p0[2]}, v1[3] = {p1[0], p1[1], p1[2]}, v2[3] = {p2[0], p2[1], p2[2]};
+        float e0[3] = {v0[0] - v2[0], v0[1] - v2[1], v0[2] - v2[2]};
+        float e1[3] = {v1[0] - v2[0], v1[1] - v2[1], v1[2] - v2[2]};
+        float c[3] = {diff_of_products(e0[1], e1[2], e1[1], e0[2]) - v2[0], // cross_product_difference(...) - v2 (Q1)
+                      diff_of_products(e0[2], e1[0], e1[2], e0[0]) - v2[1],
+                      diff_of_products(e0[0], e1[1], e1[0], e0[1]) - v2[2]};
+        float a[3][3] = {{e0[0], e1[0], c[0]}, {e0[1], e1[1], c[1]}, {e0[2], e1[2], c[2]}};
+        float det = a[0][0] * diff_of_products(a[1][1], a[2][2], a[2][1], a[1][2]) -
+                    a[0][1] * diff_of_products(a[1][0], a[2][2], a[1][2], a[2][0]) +
+                    a[0][2] * diff_of_products(a[1][0], a[2][1], a[1][1], a[2][0]);
+        float invdet = 1 / det;
+        TriRecF32 r;
+        r.m0[0] = diff_of_products(a[1][1], a[2][2], a[2][1], a[1][2]) * invdet;
+        r.m0[1] = diff_of_products(a[0][2], a[2][1], a[0][1], a[2][2]) * invdet;
+        r.m0[2] = diff_of_products(a[0][1], a[1][2], a[0][2], a[1][1]) * invdet;
+        r.m1[0] = diff_of_products(a[1][2], a[2][0], a[1][0], a[2][2]) * invdet;
+        r.m1[1] = diff_of_products(a[0][0], a[2][2], a[0][2], a[2][0]) * invdet;
+        r.m1[2] = diff_of_products(a[1][0], a[0][2], a[0][0], a[1][2]) * invdet;
+        r.m2[0] = diff_of_products(a[1][0], a[2][1], a[2][0], a[1][1]) * invdet;
+        r.m2[1] = diff_of_products(a[2][0], a[0][1], a[0][0], a[2][1]) * invdet;
+        r.m2[2] = diff_of_products(a[0][0], a[1][1], a[1][0], a[0][1]) * invdet;
+        r.v2x = v2[0];
+        r.v2y = v2[1];
+        r.v2z = v2[2];
+        mf32[g] = r;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            lo[k] = fminf(v0[k], fminf(v1[k], v2[k]));
+            hi[k] = fmaxf(v0[k], fmaxf(v1[k], v2[k]));
+            tri_bounds[6 * g + k] = lo[k];
+            tri_bounds[6 * g + 3 + k] = hi[k];
+        }
+        p = tri_prim[g];
+    }
+    // centroid bounds per primitive (normalisation box of the Morton codes): wave reduction when the whole
+    // wave belongs to one primitive (the common case), per-lane atomics otherwise
+    float cen[3] = {0.5f * (lo[0] + hi[0]), 0.5f * (lo[1] + hi[1]), 0.5f * (lo[2] + hi[2])};
+    uint32_t p0w = __shfl(p, 0, 64);
+    if (__all(p == p0w)) {
+        if (p0w == 0xffffffffu)
+            return; // a wave entirely past the end
+        float mn[3] = {cen[0], cen[1], cen[2]}, mx[3] = {cen[0], cen[1], cen[2]};
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                mn[k] = fminf(mn[k], __shfl_xor(mn[k], off, 64));
+                mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off, 64));
+            }
+        if ((threadIdx.x & 63) == 0)
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                atomicMin(prim_cbounds + 6 * p0w + k, f32_ordered(mn[k]));
+                atomicMax(prim_cbounds + 6 * p0w + 3 + k, f32_ordered(mx[k]));
+            }
+    } else if (valid) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            atomicMin(prim_cbounds + 6 * p + k, f32_ordered(cen[k]));
+            atomicMax(prim_cbounds + 6 * p + 3 + k, f32_ordered(cen[k]));
+        }
+    }
+}
+
+__device__ __forceinline__ uint32_t expand_bits10(uint32_t v) { // 10 bits -> every third bit
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t morton30(float x, float y, float z) { // x,y,z in [0,1]
+    uint32_t xi = (uint32_t)fminf(fmaxf(x * 1024.0f, 0.0f), 1023.0f);
+    uint32_t yi = (uint32_t)fminf(fmaxf(y * 1024.0f, 0.0f), 1023.0f);
+    uint32_t zi = (uint32_t)fminf(fmaxf(z * 1024.0f, 0.0f), 1023.0f);
+    return (expand_bits10(xi) << 2) | (expand_bits10(yi) << 1) | expand_bits10(zi);
+}
+
+__global__ void k_morton_keys(const float *tri_bounds, const uint32_t *tri_prim, const int *prim_cbounds, uint32_t n_tris,
+                              unsigned long long *keys, uint32_t *vals) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_tris)
+        return;
+    uint32_t p = tri_prim[g];
+    float q[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float lo = f32_unordered(prim_cbounds[6 * p + k]), hi = f32_unordered(prim_cbounds[6 * p + 3 + k]);
+        float cen = 0.5f * (tri_bounds[6 * g + k] + tri_bounds[6 * g + 3 + k]);
+        float ext = hi - lo;
+        q[k] = ext > 0.0f ? (cen - lo) / ext : 0.0f;
+    }
+    keys[g] = ((unsigned long long)p << 32) | morton30(q[0], q[1], q[2]);
+    vals[g] = g;
+}
+
+// ---- LSD radix sort: 8-bit digits, stable, (u64 key, u32 value) ---------------------------------------
+constexpr int RS_THREADS = 256;
+constexpr int RS_KPT = 8; // keys per thread
+constexpr int RS_TILE = RS_THREADS * RS_KPT;
+
+__global__ void k_radix_hist(const unsigned long long *keys, uint32_t n, int shift, uint32_t *hist, uint32_t n_blocks) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t base = blockIdx.x * RS_TILE;
+    for (int r = 0; r < RS_KPT; r++) {
+        uint32_t i = base + r * RS_THREADS + threadIdx.x;
+        if (i < n)
+            atomicAdd(&h[(keys[i] >> shift) & 0xff], 1u);
+    }
+    __syncthreads();
+    hist[threadIdx.x * n_blocks + blockIdx.x] = h[threadIdx.x]; // digit-major: a global scan yields scatter bases
+}
+
+// exclusive scan of `total` counters by one workgroup (total = 256 * n_blocks, small)
+__global__ void k_exclusive_scan(uint32_t *data, uint32_t total) {
+    __shared__ uint32_t part[RS_THREADS];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0)
+        carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < total; base += RS_THREADS) {
+        uint32_t i = base + threadIdx.x;
+        uint32_t v = i < total ? data[i] : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < RS_THREADS; off <<= 1) { // Hillis-Steele inclusive scan
+            uint32_t add = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0;
+            __syncthreads();
+            part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        uint32_t incl = part[threadIdx.x];
+        if (i < total)
+            data[i] = carry + incl - v;
+        __syncthreads();
+        if (threadIdx.x == RS_THREADS - 1)
+            carry += incl;
+        __syncthreads();
+    }
+}
+
+// Stable scatter.  Wave w of a block owns keys [w*64*KPT, (w+1)*64*KPT) of the tile, visited in rounds of
+// 64 consecutive keys.  Within a round, lanes holding the same digit find each other with 8 ballots; the
+// lowest such lane reserves their run in the wave's digit counter (LDS) — wavefront ballot + prefix.
+__global__ void k_radix_scatter(const unsigned long long *keys_in, const uint32_t *vals_in, unsigned long long *keys_out,
+                                uint32_t *vals_out, uint32_t n, int shift, const uint32_t *hist, uint32_t n_blocks) {
+    constexpr int WAVES = RS_THREADS / 64;
+    __shared__ uint32_t wcount[WAVES][256];
+    __shared__ uint32_t wbase[WAVES][256];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int d = lane; d < 256; d += 64)
+        wcount[wave][d] = 0;
+    __syncthreads();
+    unsigned long long key[RS_KPT];
+    uint32_t val[RS_KPT], rank[RS_KPT];
+    const uint32_t base = blockIdx.x * RS_TILE + wave * 64 * RS_KPT;
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < RS_KPT; r++) {
+        uint32_t i = base + r * 64 + lane;
+        bool valid = i < n;
+        key[r] = valid ? keys_in[i] : ~0ull;
+        val[r] = valid ? vals_in[i] : 0u;
+        uint32_t digit = (uint32_t)(key[r] >> shift) & 0xffu;
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            unsigned long long m = __ballot((digit >> b) & 1u);
+            peers &= ((digit >> b) & 1u) ? m : ~m;
+        }
+        uint32_t before = (uint32_t)__popcll(peers & lanes_below);
+        uint32_t start = 0;
+        if (valid && before == 0) { // leader of the run
+            start = wcount[wave][digit];
+            wcount[wave][digit] = start + (uint32_t)__popcll(peers);
+        }
+        int leader = valid ? __builtin_ctzll(peers) : (int)lane;
+        start = __shfl(start, leader, 64);
+        rank[r] = start + before;
+        // LDS counter updates of this round must be visible to the next round's leaders (same wave: in order)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // per-digit base of each wave = global base of (digit, block) + counts of the waves before it
+    for (int d = threadIdx.x; d < 256; d += RS_THREADS) {
+        uint32_t run = hist[d * n_blocks + blockIdx.x];
+        for (int w = 0; w < WAVES; w++) {
+            wbase[w][d] = run;
+            run += wcount[w][d];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_KPT; r++) {
+        uint32_t i = base + r * 64 + lane;
+        if (i < n) {
+            uint32_t digit = (uint32_t)(key[r] >> shift) & 0xffu;
+            uint32_t dst = wbase[wave][digit] + rank[r];
+            keys_out[dst] = key[r];
+            vals_out[dst] = val[r];
+        }
+    }
+}
+
+// ---- tree emission ---------------------------------------------------------------------------------
+// sorted range [l, r) of leaf k in a perfect tree of depth D over n primitives: every node splits its range
+// at l + (r-l)/2 (the reference's split_pos = size/2, object_bvh.hpp:121, on the Morton order)
+__host__ __device__ inline void leaf_range(uint32_t k, uint32_t D, uint32_t n, uint32_t &l, uint32_t &r) {
+    l = 0;
+    r = n;
+    for (int b = (int)D - 1; b >= 0; b--) {
+        uint32_t mid = l + (r - l) / 2;
+        if ((k >> b) & 1u)
+            l = mid;
+        else
+            r = mid;
+    }
+}
+
+template <typename T>
+__global__ void k_emit_triangles(const uint32_t *sorted_vals, const TriRecF32 *mf32, const float *tri_bounds,
+                                 const uint32_t *tri_prim, const lprt_mesh_vao *vaos, uint32_t n_tris, TriRec<T> *tris,
+                                 TriRecF32 *tris_f32, float *sorted_bounds) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_tris)
+        return;
+    uint32_t g = sorted_vals[s];
+    TriRecF32 f = mf32[g];
+    TriRec<T> r;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { // static_cast<Matrix<3,3,DataT>>(M2): one rounding per entry (memory.hpp:645)
+        r.m0[k] = cvt<T>(f.m0[k]);
+        r.m1[k] = cvt<T>(f.m1[k]);
+        r.m2[k] = cvt<T>(f.m2[k]);
+    }
+    r.v2x = cvt<T>(f.v2x); // vbo position in DataT
+    r.v2y = cvt<T>(f.v2y);
+    r.v2z = cvt<T>(f.v2z);
+    r.inobject_offset = 3 * g - vaos[tri_prim[g]].ebo_offset; // 3 x triangle index within the primitive
+    tris[s] = r;
+    if (tris_f32)
+        tris_f32[s] = f;
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+        sorted_bounds[6 * s + k] = tri_bounds[6 * g + k];
+}
+
+template <typename T> __device__ __forceinline__ void store_child_box(InnerNode<T> *inner, T *roots, const BlasInfo &bi, uint32_t i,
+                                                                      const float lo[3], const float hi[3]) {
+    // node i (heap index, 1-based) of this BLAS: its box lives in its parent's record, or in the root slot
+    if (i == 1) {
+        T *rb = roots + 6 * bi.root_base;
+        for (int k = 0; k < 3; k++) {
+            rb[k] = round_down<T>(lo[k]);
+            rb[3 + k] = round_up<T>(hi[k]);
+        }
+    } else {
+        InnerNode<T> *p = inner + bi.inner_base + (i >> 1) - 1;
+        T *dlo = (i & 1u) ? p->lo1 : p->lo0;
+        T *dhi = (i & 1u) ? p->hi1 : p->hi0;
+        for (int k = 0; k < 3; k++) {
+            dlo[k] = round_down<T>(lo[k]);
+            dhi[k] = round_up<T>(hi[k]);
+        }
+    }
+}
+
+// grid.y = primitive; one thread per leaf
+template <typename T>
+__global__ void k_leaf_boxes(const BlasInfo *blas, const float *sorted_bounds, uint32_t *leaf_words, InnerNode<T> *inner,
+                             T *roots) {
+    const BlasInfo bi = blas[blockIdx.y];
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bi.n_tris == 0 || k >= (1u << bi.depth))
+        return;
+    uint32_t l, r;
+    leaf_range(k, bi.depth, bi.n_tris, l, r);
+    leaf_words[bi.leaf_base + k] = (l << 1) | (r - l - 1);
+    float lo[3], hi[3];
+    const float *b = sorted_bounds + 6 * (size_t)(bi.tri_base + l);
+    for (int a = 0; a < 3; a++) {
+        lo[a] = b[a];
+        hi[a] = b[3 + a];
+    }
+    if (r - l == 2)
+        for (int a = 0; a < 3; a++) {
+            lo[a] = fminf(lo[a], b[6 + a]);
+            hi[a] = fmaxf(hi[a], b[9 + a]);
+        }
+    store_child_box<T>(inner, roots, bi, (1u << bi.depth) + k, lo, hi);
+}
+
+// one launch per depth d (deepest first): node = union of the two child boxes already stored in it
+template <typename T> __global__ void k_inner_level(const BlasInfo *blas, uint32_t d, InnerNode<T> *inner, T *roots) {
+    const BlasInfo bi = blas[blockIdx.y];
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bi.n_tris == 0 || d >= bi.depth || j >= (1u << d))
+        return;
+    uint32_t i = (1u << d) + j;
+    const InnerNode<T> nd = inner[bi.inner_base + i - 1];
+    float lo[3], hi[3];
+    for (int a = 0; a < 3; a++) { // child boxes are already DataT values: their union is exact in DataT
+        lo[a] = fminf((float)nd.lo0[a], (float)nd.lo1[a]);
+        hi[a] = fmaxf((float)nd.hi0[a], (float)nd.hi1[a]);
+    }
+    store_child_box<T>(inner, roots, bi, i, lo, hi);
+}
+
+// ---- B2: TLAS in one workgroup ---------------------------------------------------------------------
+constexpr int TLAS_MAX = 1024;
+template <typename T>
+__global__ void __launch_bounds__(256) k_build_tlas(const lprt_aabb *aabbs, uint32_t n, uint32_t D, ObjSlot<T> *slots,
+                                                    uint32_t *leaf_words, InnerNode<T> *inner, T *root) {
+    __shared__ unsigned long long keys[TLAS_MAX];
+    __shared__ float red[6][256];
+    __shared__ float lvl_lo[TLAS_MAX][3], lvl_hi[TLAS_MAX][3]; // boxes of the level being reduced
+    const uint32_t tid = threadIdx.x;
+    // 1. bounds of the box centres
+    float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+    for (uint32_t i = tid; i < n; i += 256)
+        for (int a = 0; a < 3; a++) {
+            float c = 0.5f * (aabbs[i].lower[a] + aabbs[i].upper[a]);
+            lo[a] = fminf(lo[a], c);
+            hi[a] = fmaxf(hi[a], c);
+        }
+    for (int a = 0; a < 3; a++) {
+        red[a][tid] = lo[a];
+        red[3 + a][tid] = hi[a];
+    }
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < (unsigned)s)
+            for (int a = 0; a < 3; a++) {
+                red[a][tid] = fminf(red[a][tid], red[a][tid + s]);
+                red[3 + a][tid] = fmaxf(red[3 + a][tid], red[3 + a][tid + s]);
+            }
+        __syncthreads();
+    }
+    // 2. keys = morton << 32 | index, padded with ~0 to a power of two; bitonic sort
+    uint32_t n2 = 1;
+    while (n2 < n)
+        n2 <<= 1;
+    for (uint32_t i = tid; i < n2; i += 256) {
+        unsigned long long k = ~0ull;
+        if (i < n) {
+            float q[3];
+            for (int a = 0; a < 3; a++) {
+                float ext = red[3 + a][0] - red[a][0];
+                float c = 0.5f * (aabbs[i].lower[a] + aabbs[i].upper[a]);
+                q[a] = ext > 0.0f ? (c - red[a][0]) / ext : 0.0f;
+            }
+            k = ((unsigned long long)morton30(q[0], q[1], q[2]) << 32) | i;
+        }
+        keys[i] = k;
+    }
+    __syncthreads();
+    for (uint32_t size = 2; size <= n2; size <<= 1)
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t i = tid; i < n2; i += 256) {
+                uint32_t j = i ^ stride;
+                if (j > i) {
+                    bool up = (i & size) == 0;
+                    unsigned long long a = keys[i], b = keys[j];
+                    if ((a > b) == up) {
+                        keys[i] = b;
+                        keys[j] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    // 3. slots in sorted order (aabbs_W + inscene_objid, scene_bvh.hpp:60-69)
+    for (uint32_t s = tid; s < n; s += 256) {
+        uint32_t id = (uint32_t)keys[s];
+        ObjSlot<T> o;
+        for (int a = 0; a < 3; a++) {
+            o.lo[a] = round_down<T>(aabbs[id].lower[a]);
+            o.hi[a] = round_up<T>(aabbs[id].upper[a]);
+        }
+        o.inscene_objid = id;
+        slots[s] = o;
+    }
+    // 4. leaves, then levels bottom-up through LDS
+    const uint32_t n_leaves = 1u << D;
+    for (uint32_t k = tid; k < n_leaves; k += 256) {
+        uint32_t l, r;
+        leaf_range(k, D, n, l, r);
+        leaf_words[k] = (l << 1) | (r - l - 1);
+        uint32_t id = (uint32_t)keys[l];
+        for (int a = 0; a < 3; a++) {
+            lvl_lo[k][a] = aabbs[id].lower[a];
+            lvl_hi[k][a] = aabbs[id].upper[a];
+        }
+        if (r - l == 2) {
+            uint32_t id2 = (uint32_t)keys[l + 1];
+            for (int a = 0; a < 3; a++) {
+                lvl_lo[k][a] = fminf(lvl_lo[k][a], aabbs[id2].lower[a]);
+                lvl_hi[k][a] = fmaxf(lvl_hi[k][a], aabbs[id2].upper[a]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int d = (int)D; d >= 0; d--) { // boxes of depth d are in lvl_*[0 .. 2^d)
+        uint32_t cnt = 1u << d;
+        float nlo[2][3], nhi[2][3]; // a thread handles at most TLAS_MAX/256/2 = 2 parents per level
+        uint32_t np = 0;
+        for (uint32_t j = tid; j < cnt; j += 256) {
+            uint32_t i = cnt + j; // heap index
+            if (i == 1) {
+                for (int a = 0; a < 3; a++) {
+                    root[a] = round_down<T>(lvl_lo[0][a]);
+                    root[3 + a] = round_up<T>(lvl_hi[0][a]);
+                }
+            } else {
+                InnerNode<T> *p = inner + (i >> 1) - 1;
+                T *dlo = (i & 1u) ? p->lo1 : p->lo0;
+                T *dhi = (i & 1u) ? p->hi1 : p->hi0;
+                for (int a = 0; a < 3; a++) {
+                    dlo[a] = round_down<T>(lvl_lo[j][a]);
+                    dhi[a] = round_up<T>(lvl_hi[j][a]);
+                }
+            }
+        }
+        if (d > 0)
+            for (uint32_t j = tid; j < (cnt >> 1); j += 256, np++)
+                for (int a = 0; a < 3; a++) {
+                    nlo[np][a] = fminf(lvl_lo[2 * j][a], lvl_lo[2 * j + 1][a]);
+                    nhi[np][a] = fmaxf(lvl_hi[2 * j][a], lvl_hi[2 * j + 1][a]);
+                }
+        __syncthreads();
+        if (d > 0) {
+            np = 0;
+            for (uint32_t j = tid; j < (cnt >> 1); j += 256, np++)
+                for (int a = 0; a < 3; a++) {
+                    lvl_lo[j][a] = nlo[np][a];
+                    lvl_hi[j][a] = nhi[np][a];
+                }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- host drivers -------------------------------------------------------------------------------------
+static inline uint32_t floor_log2(uint32_t n) {
+    uint32_t d = 0;
+    while ((2u << d) <= n)
+        d++;
+    return d;
+}
+
+template <typename T> void GeometryStore<T>::upload(hipStream_t st, const lprt_vertex *vbo, uint32_t nv, const uint32_t *ebo, uint32_t ni,
+                                                    const lprt_mesh_vao *vaos, uint32_t nvaos) {
+    n_vertices = nv;
+    n_indices = ni;
+    n_tris = ni / 3;
+    n_vaos = nvaos;
+    host_vaos.assign(vaos, vaos + nvaos);
+    d_vbo32.reserve(sizeof(lprt_vertex) * (size_t)std::max(nv, 1u));
+    d_vbo.reserve(sizeof(Vertex<T>) * (size_t)std::max(nv, 1u));
+    d_ebo.reserve(sizeof(uint32_t) * (size_t)std::max(ni, 1u));
+    d_vaos.reserve(sizeof(lprt_mesh_vao) * (size_t)std::max(nvaos, 1u));
+    if (nv)
+        LPRT_HIP(hipMemcpyAsync(d_vbo32.ptr, vbo, sizeof(lprt_vertex) * (size_t)nv, hipMemcpyHostToDevice, st));
+    if (ni)
+        LPRT_HIP(hipMemcpyAsync(d_ebo.ptr, ebo, sizeof(uint32_t) * (size_t)ni, hipMemcpyHostToDevice, st));
+    if (nvaos)
+        LPRT_HIP(hipMemcpyAsync(d_vaos.ptr, vaos, sizeof(lprt_mesh_vao) * (size_t)nvaos, hipMemcpyHostToDevice, st));
+    // triangle -> primitive map and per-primitive tree geometry (host arithmetic on sizes only)
+    std::vector<uint32_t> tri_prim(std::max(n_tris, 1u), 0xffffffffu);
+    host_blas.assign(nvaos, BlasInfo{});
+    uint32_t inner_total = 0, leaf_total = 0;
+    max_depth = 0;
+    max_leaves = 1;
+    for (uint32_t p = 0; p < nvaos; p++) {
+        BlasInfo &bi = host_blas[p];
+        bi.n_tris = vaos[p].ebo_length / 3;
+        bi.tri_base = vaos[p].ebo_offset / 3;
+        bi.depth = bi.n_tris ? floor_log2(bi.n_tris) : 0;
+        bi.inner_base = inner_total;
+        bi.leaf_base = leaf_total;
+        bi.root_base = p;
+        if (bi.n_tris) {
+            inner_total += (1u << bi.depth) - 1;
+            leaf_total += 1u << bi.depth;
+            max_depth = std::max(max_depth, bi.depth);
+            max_leaves = std::max(max_leaves, 1u << bi.depth);
+        }
+        for (uint32_t t = 0; t < bi.n_tris; t++)
+            tri_prim[bi.tri_base + t] = p;
+    }
+    n_inner = inner_total;
+    n_leaves = leaf_total;
+    d_tri_prim.reserve(sizeof(uint32_t) * tri_prim.size());
+    LPRT_HIP(hipMemcpyAsync(d_tri_prim.ptr, tri_prim.data(), sizeof(uint32_t) * tri_prim.size(), hipMemcpyHostToDevice, st));
+    d_blas.reserve(sizeof(BlasInfo) * (size_t)std::max(nvaos, 1u));
+    if (nvaos)
+        LPRT_HIP(hipMemcpyAsync(d_blas.ptr, host_blas.data(), sizeof(BlasInfo) * (size_t)nvaos, hipMemcpyHostToDevice, st));
+    size_t nt = std::max(n_tris, 1u);
+    d_mf32.reserve(sizeof(TriRecF32) * nt);
+    d_tri_bounds.reserve(sizeof(float) * 6 * nt);
+    d_sorted_bounds.reserve(sizeof(float) * 6 * nt);
+    d_prim_cbounds.reserve(sizeof(int) * 6 * (size_t)std::max(nvaos, 1u));
+    d_keys[0].reserve(sizeof(unsigned long long) * nt);
+    d_keys[1].reserve(sizeof(unsigned long long) * nt);
+    d_vals[0].reserve(sizeof(uint32_t) * nt);
+    d_vals[1].reserve(sizeof(uint32_t) * nt);
+    uint32_t n_blocks = (n_tris + RS_TILE - 1) / RS_TILE;
+    d_hist.reserve(sizeof(uint32_t) * 256 * (size_t)std::max(n_blocks, 1u));
+    d_tris.reserve(sizeof(TriRec<T>) * nt);
+    if (Num<T>::is_half)
+        d_tris_f32.reserve(sizeof(TriRecF32) * nt);
+    d_inner.reserve(sizeof(InnerNode<T>) * (size_t)std::max(n_inner, 1u));
+    d_leaf.reserve(sizeof(uint32_t) * (size_t)std::max(n_leaves, 1u));
+    d_roots.reserve(sizeof(T) * 6 * (size_t)std::max(nvaos, 1u));
+    LPRT_HIP(hipStreamSynchronize(st)); // host staging vectors above go out of scope
+    if (nv)
+        hipLaunchKernelGGL(k_convert_vertices<T>, dim3((nv + 255) / 256), dim3(256), 0, st, d_vbo32.as<lprt_vertex>(),
+                           d_vbo.as<Vertex<T>>(), nv);
+    built = false;
+}
+
+template <typename T> void GeometryStore<T>::build_blas(hipStream_t st) {
+    if (n_tris == 0 || n_vaos == 0) {
+        built = true;
+        return;
+    }
+    const uint32_t tb = (n_tris + 255) / 256;
+    // centroid bounds start at (+max, -max) in ordered-int space
+    std::vector<int> init(6 * (size_t)n_vaos);
+    for (uint32_t p = 0; p < n_vaos; p++)
+        for (int k = 0; k < 3; k++) {
+            init[6 * p + k] = 0x7fffffff;
+            init[6 * p + 3 + k] = (int)0x80000000;
+        }
+    LPRT_HIP(hipMemcpyAsync(d_prim_cbounds.ptr, init.data(), sizeof(int) * init.size(), hipMemcpyHostToDevice, st));
+    LPRT_HIP(hipStreamSynchronize(st));
+    hipLaunchKernelGGL(k_tri_prepare, dim3(tb), dim3(256), 0, st, d_vbo32.as<lprt_vertex>(), d_ebo.as<uint32_t>(), n_tris,
+                       d_tri_prim.as<uint32_t>(), d_mf32.as<TriRecF32>(), d_tri_bounds.as<float>(), d_prim_cbounds.as<int>());
+    hipLaunchKernelGGL(k_morton_keys, dim3(tb), dim3(256), 0, st, d_tri_bounds.as<float>(), d_tri_prim.as<uint32_t>(),
+                       d_prim_cbounds.as<int>(), n_tris, d_keys[0].as<unsigned long long>(), d_vals[0].as<uint32_t>());
+    // radix passes over the 30 Morton bits + the primitive bits (key = prim << 32 | morton)
+    uint32_t prim_bits = 0;
+    while ((1u << prim_bits) < n_vaos)
+        prim_bits++;
+    std::vector<int> shifts = {0, 8, 16, 24};
+    for (uint32_t b = 0; b < prim_bits; b += 8)
+        shifts.push_back(32 + (int)b);
+    const uint32_t n_blocks = (n_tris + RS_TILE - 1) / RS_TILE;
+    int cur = 0;
+    for (int shift : shifts) {
+        hipLaunchKernelGGL(k_radix_hist, dim3(n_blocks), dim3(RS_THREADS), 0, st, d_keys[cur].as<unsigned long long>(), n_tris,
+                           shift, d_hist.as<uint32_t>(), n_blocks);
+        hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(RS_THREADS), 0, st, d_hist.as<uint32_t>(), 256 * n_blocks);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(n_blocks), dim3(RS_THREADS), 0, st, d_keys[cur].as<unsigned long long>(),
+                           d_vals[cur].as<uint32_t>(), d_keys[cur ^ 1].as<unsigned long long>(), d_vals[cur ^ 1].as<uint32_t>(),
+                           n_tris, shift, d_hist.as<uint32_t>(), n_blocks);
+        cur ^= 1;
+    }
+    sorted_buf = cur;
+    hipLaunchKernelGGL(k_emit_triangles<T>, dim3(tb), dim3(256), 0, st, d_vals[cur].as<uint32_t>(), d_mf32.as<TriRecF32>(),
+                       d_tri_bounds.as<float>(), d_tri_prim.as<uint32_t>(), d_vaos.as<lprt_mesh_vao>(), n_tris,
+                       d_tris.as<TriRec<T>>(), Num<T>::is_half ? d_tris_f32.as<TriRecF32>() : nullptr,
+                       d_sorted_bounds.as<float>());
+    hipLaunchKernelGGL(k_leaf_boxes<T>, dim3((max_leaves + 255) / 256, n_vaos), dim3(256), 0, st, d_blas.as<BlasInfo>(),
+                       d_sorted_bounds.as<float>(), d_leaf.as<uint32_t>(), d_inner.as<InnerNode<T>>(), d_roots.as<T>());
+    for (int d = (int)max_depth - 1; d >= 0; d--)
+        hipLaunchKernelGGL(k_inner_level<T>, dim3(((1u << d) + 255) / 256, n_vaos), dim3(256), 0, st, d_blas.as<BlasInfo>(),
+                           (uint32_t)d, d_inner.as<InnerNode<T>>(), d_roots.as<T>());
+    LPRT_HIP(hipGetLastError());
+    built = true;
+}
+
+template <typename T> void TlasStore<T>::build(hipStream_t st, const lprt_aabb *aabbs, uint32_t n) {
+    n_objects = n;
+    depth = n ? floor_log2(n) : 0;
+    d_aabbs.reserve(sizeof(lprt_aabb) * (size_t)std::max(n, 1u));
+    d_slots.reserve(sizeof(ObjSlot<T>) * (size_t)std::max(n, 1u));
+    d_leaf.reserve(sizeof(uint32_t) * (size_t)(1u << depth));
+    d_inner.reserve(sizeof(InnerNode<T>) * (size_t)std::max((1u << depth) - 1, 1u));
+    d_root.reserve(sizeof(T) * 6);
+    if (n == 0)
+        return;
+    LPRT_HIP(hipMemcpyAsync(d_aabbs.ptr, aabbs, sizeof(lprt_aabb) * (size_t)n, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_build_tlas<T>, dim3(1), dim3(256), 0, st, d_aabbs.as<lprt_aabb>(), n, depth, d_slots.as<ObjSlot<T>>(),
+                       d_leaf.as<uint32_t>(), d_inner.as<InnerNode<T>>(), d_root.as<T>());
+    LPRT_HIP(hipGetLastError());
+}
+
+template struct GeometryStore<float>;
+template struct GeometryStore<h16>;
+template struct TlasStore<float>;
+template struct TlasStore<h16>;
+
+} // namespace lprt

@@ -1,0 +1,31 @@
+// Owners of the static geometry / BLAS set and of the per-frame TLAS.
+#pragma once
+#include "ctx.hpp"
+#include <algorithm>
+
+namespace lprt {
+
+template <typename T> struct GeometryStore {
+    uint32_t n_vertices = 0, n_indices = 0, n_tris = 0, n_vaos = 0, n_inner = 0, n_leaves = 0, max_depth = 0, max_leaves = 1;
+    bool built = false;
+    int sorted_buf = 0;
+    std::vector<lprt_mesh_vao> host_vaos;
+    std::vector<BlasInfo> host_blas;
+    DevBuf d_vbo32, d_vbo, d_ebo, d_vaos, d_tri_prim, d_blas;
+    DevBuf d_mf32, d_tri_bounds, d_sorted_bounds, d_prim_cbounds, d_keys[2], d_vals[2], d_hist;
+    DevBuf d_tris, d_tris_f32, d_inner, d_leaf, d_roots;
+
+    // RDResource::{objects_vbo, objects_ebo, objects_vao} + vertex conversion (memory.hpp:568-619)
+    void upload(hipStream_t st, const lprt_vertex *vbo, uint32_t nv, const uint32_t *ebo, uint32_t ni, const lprt_mesh_vao *vaos,
+                uint32_t nvaos);
+    // compute_m + ObjectBVH for every primitive, all on the device
+    void build_blas(hipStream_t st);
+};
+
+template <typename T> struct TlasStore {
+    uint32_t n_objects = 0, depth = 0;
+    DevBuf d_aabbs, d_slots, d_leaf, d_inner, d_root;
+    void build(hipStream_t st, const lprt_aabb *aabbs, uint32_t n);
+};
+
+} // namespace lprt

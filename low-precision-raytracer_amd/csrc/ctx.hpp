@@ -1,0 +1,116 @@
+// Host-side context: owns every device allocation of one renderer instance.
+// Replaces the owners behind the reference's operator surface: RDResource (memory.hpp:568-648),
+// CUDARenderGIData (cuda.hpp:635-792), RTRTProcedureBuffer + SVGFBuffer (cuda.hpp:1117-1166, 1475-1634),
+// GBuffer (memory.hpp:155-253) and the output surface (imgui_window.cu:349-357).
+#pragma once
+#include "types.hpp"
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+
+namespace lprt {
+
+struct HipError {
+    hipError_t code;
+    const char *what;
+    const char *file;
+    int line;
+};
+#define LPRT_HIP(expr)                                                                                                 \
+    do {                                                                                                               \
+        hipError_t _e = (expr);                                                                                        \
+        if (_e != hipSuccess)                                                                                          \
+            throw ::lprt::HipError{_e, #expr, __FILE__, __LINE__};                                                     \
+    } while (0)
+
+// plain device allocation that can grow; contents are not preserved on growth
+struct DevBuf {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    void reserve(size_t n) {
+        if (n <= bytes)
+            return;
+        release();
+        LPRT_HIP(hipMalloc(&ptr, n));
+        bytes = n;
+    }
+    void release() {
+        if (ptr)
+            (void)hipFree(ptr);
+        ptr = nullptr;
+        bytes = 0;
+    }
+    template <typename U> U *as() const { return static_cast<U *>(ptr); }
+    ~DevBuf() { release(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+};
+
+struct StageTimer {
+    bool enabled = false;
+    float ms[LPRT_STAGE_COUNT] = {};
+    uint32_t launches[LPRT_STAGE_COUNT] = {};
+    struct Pending {
+        int stage;
+        hipEvent_t a, b;
+    };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+};
+
+// per-pixel planes of one SVGF lobe (SVGFBuffer, cuda.hpp:1117-1166); colour and variance travel
+// together as one 4-vector {r,g,b,var} so a filter tap is a single 16-B/8-B load
+template <typename T> struct SvgfLobe {
+    V4<T> *cv_a;   // colour in/out (the mul_gi_* plane) + var
+    V4<T> *cv_b;   // color_history (level-1 output; next frame's temporal history) + var
+    V4<T> *cv_c;   // color_buffer + var
+    T *illum;      // illum_buffer
+    T *miu1_hist, *miu2_hist; // miu1_1 / miu2_1
+    T *miu1_cur, *miu2_cur;   // miu1_2 / miu2_2
+};
+
+template <typename T> struct TemporalMapT { // TemporalMap<DataT>, cuda.hpp:1055-1065 (26 B f16 / 36 B f32 -> padded)
+    T weights[4];
+    uint16_t pos[4][2];
+    uint32_t frame_count;
+};
+
+// every per-pixel work buffer (RTRTProcedureBuffer<DataT,4>::Ref, cuda.hpp:1538-1561) for the window
+template <typename T> struct FrameDev {
+    Window win;
+    // G-buffer (7 surfaces, cuda.hpp:153-159)
+    V4<T> *g_position, *g_normal_depth, *g_tangent, *g_uv;
+    uint32_t *g_color, *g_objid, *g_offset;
+    // shade <-> trace hand-over
+    V4<T> *gi_multiplier;   // gi_material_multiplier[0] (w: unused)
+    V4<T> *gi_multiplier1;  // gi_material_multiplier[1] — never read by the reference, kept for completeness
+    V4<T> *intensity0, *intensity1;
+    V4<T> *view_direction;
+    uint2 *skips;
+    V4<T> *gi_source, *gi_direction; // TraceGICommand (x/y implicit: the pixel itself)
+    uint8_t *gi_valid;
+    // light commands, SoA by slot: slot s of pixel p at [s * npix + p]
+    V4<T> *lc_dir_maxt;     // direction.xyz, maximum_t
+    V4<T> *lc_multiplier;   // material_multiplier.xyz
+    uint8_t *lc_mask;       // bit s set: slot s active (slot != 255)
+    // PixelShaderInput (cuda.hpp:1034-1048), SoA
+    V4<T> *sc_position, *sc_normal, *sc_tangent, *sc_color, *sc_uv;
+    uint32_t *sc_type, *sc_materialid, *sc_objid, *sc_offset;
+    // filterable cache
+    V4<T> *albedo, *color_inprogress, *taa_history;
+    float4 *acc_color, *acc_gi_colored, *acc_gi_white; // spp accumulators (f32)
+    V4<T> *raw_color, *raw_gi_colored, *raw_gi_white;  // pre-denoise copies for parity read-back
+    SvgfLobe<T> lobe[2];
+    V2<T> *depth_gradient;
+    TemporalMapT<T> *svgf_map, *taa_map;
+    uint8_t *valid_frame_count, *prev_frame_count;
+    uint2 *last_frame_id;
+    M4<T> *last_frame_L2W;
+    M4<T> last_frame_W2C;
+    float4 *output; // RGBA32F
+    // RNG: xorwow state planes v0..v4 for the window's pixels (d is uniform per seed)
+    uint32_t *rng_state; // [5][npix]
+};
+
+} // namespace lprt

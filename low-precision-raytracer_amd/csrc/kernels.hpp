@@ -1,0 +1,41 @@
+// Host-callable launchers of the device kernels (one explicit instantiation per DataT).
+#pragma once
+#include "ctx.hpp"
+
+namespace lprt {
+
+// trace_kernels.hip
+template <typename T>
+void launch_trace_rays(hipStream_t st, const SceneDev<T> &sc, const lprt_ray *rays, uint32_t n, bool any, lprt_hit *hits, Counters *counters);
+template <typename T> void launch_convert_objects(hipStream_t st, const lprt_object *in, ObjConst<T> *out, uint32_t n);
+template <typename T> void launch_convert_materials(hipStream_t st, const lprt_material *in, MaterialT<T> *out, uint32_t n);
+template <typename T> void launch_convert_lights(hipStream_t st, const lprt_light *in, LightT<T> *out, uint32_t n);
+template <typename T> void launch_convert_mat4(hipStream_t st, const float *in, M4<T> *out, uint32_t n);
+
+
+// pipeline.hip
+template <typename T> void launch_fill_gbuffer(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, Counters *c);
+template <typename T> void launch_temporal_map(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, uint32_t rng_d);
+template <typename T> void launch_shade(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, bool no_gi, uint32_t rng_d);
+template <typename T> void launch_trace_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, Counters *c);
+template <typename T> void launch_trace_gi(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, Counters *c);
+template <typename T> void launch_compose(hipStream_t st, const FrameDev<T> &fb, bool gi_on, bool add_direct, uint32_t sample, uint32_t spp);
+
+// svgf.hip
+template <typename T> void launch_svgf(hipStream_t st, FrameDev<T> &fb, float color_w, float moments_w);
+template <typename T>
+void launch_finalize(hipStream_t st, const SceneDev<T> &sc, FrameDev<T> &fb, const V4<T> *gi_colored, const V4<T> *gi_white, V4<T> *taa_next,
+                     bool add_colored, bool add_white, bool demodulate, float taa_w, uint32_t n_objects);
+template <typename T> void launch_read_v4(hipStream_t st, const V4<T> *src, float *dst, uint32_t n, int channels);
+void launch_read_u32(hipStream_t st, const uint32_t *src, float *dst, uint32_t n, bool rgba8);
+
+// rng.hip
+struct RngStore {
+    bool ready = false;
+    DevBuf d_mats, d_w3, d_w2, d_w1;
+    void init(hipStream_t st);
+    // xorwow states of curand_init(seed, n, 0) for global pixels n in [first, first + count) -> planes[5][count]; returns d
+    uint32_t generate(hipStream_t st, uint64_t seed, uint32_t total_pixels, uint32_t first, uint32_t count, uint32_t *planes);
+};
+
+} // namespace lprt

@@ -1,0 +1,566 @@
+// Per-frame wavefront pipeline kernels: primary rays -> G-buffer, temporal reprojection maps, shade,
+// shadow/GI tracing, composition.  One thread per pixel of the window; all per-pixel planes are SoA or
+// 8/16-byte vectors so that a wave's accesses are contiguous.
+//
+// Reference stage order: Renderer::render_gbuffer + render_cuda (rt/gui/imgui_window.cu:121-329).
+// Differences that do not change results: the five per-frame memsets (imgui_window.cu:136-140) are gone
+// because every kernel writes all of its outputs; the 4N-thread trace_di_light + accumulate_di_light pair
+// is one kernel that walks a pixel's active light slots in slot order; TraceLightCommand /
+// TraceGICommand / PixelShaderInput AoS records are split into planes.
+#include "kernels.hpp"
+#include "shade.hpp"
+#include "trace.hpp"
+
+namespace lprt {
+
+template <typename T> LPRT_DEV V3<T> ld3(const T *p) { return mk3(p[0], p[1], p[2]); }
+LPRT_DEV uint32_t pack_rgba8(uint32_t r, uint32_t g, uint32_t b, uint32_t a) { return r | (g << 8) | (b << 16) | (a << 24); }
+
+// attribute interpolation shared by fill_gbuffer (cuda.hpp:967-987) and trace_gi (cuda.hpp:2107-2128)
+template <typename T> struct HitAttr {
+    V3<T> position, normal, tangent, color;
+    V2<T> uv0, uv1;
+};
+template <typename T> LPRT_DEV HitAttr<T> interpolate_hit(const SceneDev<T> &sc, const Isect<T> &is) {
+    HitAttr<T> h{};
+    LPRT_CHECKA_RET(sc, is.inscene_objid < sc.lim_objects, 101, is.inscene_objid, sc.lim_objects, h);
+    const ObjConst<T> *oc = sc.objects + is.inscene_objid;
+    LPRT_CHECKA_RET(sc, oc->objectid < sc.n_vaos, 102, oc->objectid, sc.n_vaos, h);
+    const lprt_mesh_vao vao = sc.vaos[oc->objectid];
+    LPRT_CHECKA_RET(sc, vao.ebo_offset + is.inobject_offset + 2 < sc.lim_indices, 103, vao.ebo_offset, is.inobject_offset, h);
+    const uint32_t *e = sc.ebo + vao.ebo_offset + is.inobject_offset;
+    LPRT_CHECKA_RET(sc, e[0] < sc.lim_vertices && e[1] < sc.lim_vertices && e[2] < sc.lim_vertices, 104, e[0], e[2], h);
+    const Vertex<T> a = sc.vbo[e[0]], b = sc.vbo[e[1]], c = sc.vbo[e[2]];
+    V3<T> position = lerp3(is.bary, ld3(a.position), ld3(b.position), ld3(c.position));
+    V3<T> normal = normalized(lerp3(is.bary, ld3(a.normal), ld3(b.normal), ld3(c.normal)));
+    h.color = lerp3(is.bary, ld3(a.color), ld3(b.color), ld3(c.color));
+    V3<T> tangent = normalized(lerp3(is.bary, ld3(a.tangent), ld3(b.tangent), ld3(c.tangent)));
+    h.uv0 = lerp2(is.bary, V2<T>{a.uv0[0], a.uv0[1]}, V2<T>{b.uv0[0], b.uv0[1]}, V2<T>{c.uv0[0], c.uv0[1]});
+    h.uv1 = lerp2(is.bary, V2<T>{a.uv1[0], a.uv1[1]}, V2<T>{b.uv1[0], b.uv1[1]}, V2<T>{c.uv1[0], c.uv1[1]});
+    h.normal = normalized(xform_dir(oc->L2W, normal));
+    h.tangent = normalized(xform_dir(oc->L2W, tangent));
+    h.position = xform_pos(oc->L2W, position);
+    return h;
+}
+
+// ---- G2: fill_gbuffer_in_cuda (cuda.hpp:950-1012) ---------------------------------------------------------
+template <typename T, bool COUNT>
+__global__ void __launch_bounds__(256) k_fill_gbuffer(SceneDev<T> sc, FrameDev<T> fb, Counters *counters) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    Cnt<COUNT> cnt;
+    if (p < fb.win.npix()) {
+        const uint32_t x = p % fb.win.W, y = fb.win.row_begin + p / fb.win.W;
+        RayT<T> ray = primary_ray(sc, fb.win.W, fb.win.H, x, y);
+        Isect<T> is = cast_ray<T, false, COUNT>(sc, ray, 0xffffffffu, 0u, (T)0, cvt<T>(1e5f), cnt);
+        // All seven planes are written by ONE unconditional store sequence below.  (An if/else with stores in
+        // both arms made hipcc 7.2 sink the stores into a block that indexed them with a register only the hit
+        // arm had defined: the miss lanes of a mixed wave stored through garbage addresses.)
+        const T one = (T)1, zero = (T)0;
+        V4<T> o_pos = mk4(zero, zero, zero, zero), o_nd = o_pos, o_tan = o_pos, o_uv = o_pos;
+        uint32_t o_col = 0u, o_obj = 0u, o_off = 0u;
+        if (is.hit) {
+            HitAttr<T> h = interpolate_hit(sc, is);
+            o_pos = mk4(h.position.x, h.position.y, h.position.z, one);
+            o_nd = mk4(h.normal.x, h.normal.y, h.normal.z, one); // Q11: traced depth = 1
+            o_tan = mk4(h.tangent.x, h.tangent.y, h.tangent.z, one);
+            // to_color_uchar (cuda.hpp:898-902): int(0.5f + c * DataT(255)), clamped
+            int r = clip_both<int>(0, 255, f2i(0.5f + (float)(h.color.x * cvt<T>(255.f))));
+            int g = clip_both<int>(0, 255, f2i(0.5f + (float)(h.color.y * cvt<T>(255.f))));
+            int b = clip_both<int>(0, 255, f2i(0.5f + (float)(h.color.z * cvt<T>(255.f))));
+            o_col = pack_rgba8((uint32_t)r, (uint32_t)g, (uint32_t)b, 255u);
+            o_uv = mk4(h.uv0.x, h.uv0.y, h.uv1.x, h.uv1.y);
+            o_obj = is.inscene_objid;
+            o_off = is.inobject_offset;
+        }
+        fb.g_position[p] = o_pos;
+        fb.g_normal_depth[p] = o_nd;
+        fb.g_tangent[p] = o_tan;
+        fb.g_color[p] = o_col;
+        fb.g_uv[p] = o_uv;
+        fb.g_objid[p] = o_obj;
+        fb.g_offset[p] = o_off;
+    }
+    flush_counters<COUNT>(cnt, counters);
+}
+
+// ---- V1: generate_temporal_map_step1/2 (cuda.hpp:2265-2416) ------------------------------------------------
+// `first` = no history yet (DEVIATION Q7: frame_count = 0 everywhere).  The neighbours' previous frame counts
+// come from a snapshot plane (prev_frame_count), which replaces the reference's racy two-step scheme.
+template <typename T>
+__global__ void __launch_bounds__(256) k_temporal_map(SceneDev<T> sc, FrameDev<T> fb, int first, uint32_t rng_d) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t npix = fb.win.npix();
+    if (p >= npix)
+        return;
+    const T zero = (T)0;
+    TemporalMapT<T> sm, tm;
+    for (int i = 0; i < 4; i++) {
+        sm.weights[i] = zero;
+        tm.weights[i] = zero;
+        sm.pos[i][0] = sm.pos[i][1] = tm.pos[i][0] = tm.pos[i][1] = 0;
+    }
+    sm.frame_count = 0;
+    tm.frame_count = 0;
+    const bool empty = (fb.g_color[p] >> 24) == 0;
+    if (!empty && !first) {
+        const int W = (int)fb.win.W, H = (int)fb.win.H, r0 = (int)fb.win.row_begin, r1 = (int)fb.win.row_end;
+        const ObjConst<T> *oc = sc.objects + fb.g_objid[p];
+        const uint32_t objectid = oc->objectid;
+        V4<T> cW = fb.g_position[p];
+        cW.w = (T)1;
+        V4<T> cL = mul(oc->W2L, cW);
+        V4<T> cWlf = mul(fb.last_frame_L2W[objectid], cL);
+        V4<T> cC = mul(fb.last_frame_W2C, cWlf);
+        const T one = (T)1, two = (T)2;
+        T g_fx = tdiv(one + tdiv(cC.x, cC.w), two) * cvt<T>((float)W);
+        T g_fy = tdiv(one + tdiv(cC.y, cC.w), two) * cvt<T>((float)H);
+        // rows outside this GPU's window count as outside the image (sharded frames)
+        { // svgf 2x2, pixel centre
+            T fx = g_fx - cvt<T>(0.5f), fy = g_fy - cvt<T>(0.5f);
+            int lx = f2i((float)fx), ly = f2i((float)fy), ux = lx + 1, uy = ly + 1;
+            int nx[4] = {lx, lx, ux, ux}, ny[4] = {ly, uy, ly, uy};
+            T tux = cvt<T>((float)ux), tuy = cvt<T>((float)uy), tlx = cvt<T>((float)lx), tly = cvt<T>((float)ly);
+            T wts[4] = {(tux - fx) * (tuy - fy), (tux - fx) * (fy - tly), (fx - tlx) * (tuy - fy), (fx - tlx) * (fy - tly)};
+            T total = zero;
+            int count = 0;
+            for (int i = 0; i < 4; i++)
+                if (nx[i] >= 0 && nx[i] < W && ny[i] >= r0 && ny[i] < r1) {
+                    uint32_t q = (uint32_t)(ny[i] - r0) * (uint32_t)W + (uint32_t)nx[i];
+                    if (fb.last_frame_id[q].x == objectid) {
+                        count = max(count, (int)fb.prev_frame_count[q]);
+                        sm.weights[i] = wts[i];
+                        total = total + wts[i];
+                        sm.pos[i][0] = (uint16_t)nx[i];
+                        sm.pos[i][1] = (uint16_t)(ny[i] - r0);
+                    }
+                }
+            if (!(total == zero)) {
+                for (int i = 0; i < 4; i++) {
+                    if (count < 255)
+                        count += 1; // Q6: +4 per frame
+                    sm.weights[i] = tdiv(sm.weights[i], total);
+                }
+                sm.frame_count = (uint32_t)count;
+            }
+        }
+        { // taa 2x2, jittered with two uniforms of curand_init(seed A, pixel, 0)
+            Xorwow st;
+            const uint32_t *rs = fb.rng_state;
+            st.v0 = rs[p];
+            st.v1 = rs[npix + p];
+            st.v2 = rs[2 * npix + p];
+            st.v3 = rs[3 * npix + p];
+            st.v4 = rs[4 * npix + p];
+            st.d = rng_d;
+            st.bm_flag = 0;
+            st.bm_extra = 0.f;
+            T fx = g_fx - cvt<T>(xorwow_uniform(st));
+            T fy = g_fy - cvt<T>(xorwow_uniform(st));
+            int lx = f2i((float)fx), ly = f2i((float)fy), ux = lx + 1, uy = ly + 1;
+            int nx[4] = {lx, lx, ux, ux}, ny[4] = {ly, uy, ly, uy};
+            T tux = cvt<T>((float)ux), tuy = cvt<T>((float)uy), tlx = cvt<T>((float)lx), tly = cvt<T>((float)ly);
+            T wts[4] = {(tux - fx) * (tuy - fy), (tux - fx) * (fy - tly), (fx - tlx) * (tuy - fy), (fx - tlx) * (fy - tly)};
+            T total = zero;
+            bool same = false;
+            for (int i = 0; i < 4; i++)
+                if (nx[i] >= 0 && nx[i] < W && ny[i] >= r0 && ny[i] < r1) {
+                    uint32_t q = (uint32_t)(ny[i] - r0) * (uint32_t)W + (uint32_t)nx[i];
+                    tm.weights[i] = wts[i];
+                    total = total + wts[i];
+                    tm.pos[i][0] = (uint16_t)nx[i];
+                    tm.pos[i][1] = (uint16_t)(ny[i] - r0);
+                    if (fb.last_frame_id[q].x == objectid)
+                        same = true;
+                }
+            if (same) {
+                for (int i = 0; i < 4; i++)
+                    tm.weights[i] = tdiv(tm.weights[i], total);
+                tm.frame_count = 1;
+            }
+        }
+    }
+    fb.svgf_map[p] = sm;
+    fb.taa_map[p] = tm;
+    fb.valid_frame_count[p] = (uint8_t)sm.frame_count;
+}
+
+// ---- S: shade<T,4,FIRST_ROUND,NO_GI> (cuda.hpp:1751-2056) ----------------------------------------------------
+template <typename T, bool FIRST, bool NO_GI>
+__global__ void __launch_bounds__(256) k_shade(SceneDev<T> sc, FrameDev<T> fb, uint32_t rng_d) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t npix = fb.win.npix();
+    if (p >= npix)
+        return;
+    const uint32_t x = p % fb.win.W, y = fb.win.row_begin + p / fb.win.W;
+    const T zero = (T)0, one = (T)1;
+    const V4<T> zero4 = mk4(zero, zero, zero, zero);
+    V4<T> *intensity = FIRST ? fb.intensity0 : fb.intensity1;
+
+    V3<T> position, raw_normal, raw_tangent, vertex_color;
+    MaterialT<T> material;
+    uint32_t inscene_objid, inobject_offset, objectid;
+    bool live = true;
+    if (FIRST) {
+        const uint32_t c4 = fb.g_color[p];
+        // to_color_float (cuda.hpp:890-892): DataT(c / 255.f)
+        vertex_color = mk3(cvt<T>((float)(c4 & 255u) / 255.f), cvt<T>((float)((c4 >> 8) & 255u) / 255.f),
+                           cvt<T>((float)((c4 >> 16) & 255u) / 255.f));
+        if ((c4 >> 24) == 0) {
+            live = false; // empty pixel (cuda.hpp:1781-1796); skybox is handled in compose when valid
+        } else {
+            inscene_objid = fb.g_objid[p];
+            inobject_offset = fb.g_offset[p];
+            position = xyz(fb.g_position[p]);
+            raw_normal = xyz(fb.g_normal_depth[p]);
+            raw_tangent = xyz(fb.g_tangent[p]);
+            const ObjConst<T> *oc = sc.objects + inscene_objid;
+            material = sc.materials[oc->materialid];
+            objectid = oc->objectid;
+        }
+    } else {
+        if (fb.sc_type[p] != 1u) { // INVALID or SKYBOX (cuda.hpp:1819-1833); Q5: invalid skybox contributes 0
+            live = false;
+        } else {
+            vertex_color = xyz(fb.sc_color[p]);
+            inscene_objid = fb.sc_objid[p];
+            inobject_offset = fb.sc_offset[p];
+            position = xyz(fb.sc_position[p]);
+            raw_normal = xyz(fb.sc_normal[p]);
+            raw_tangent = xyz(fb.sc_tangent[p]);
+            material = sc.materials[fb.sc_materialid[p]];
+            objectid = sc.objects[inscene_objid].objectid;
+        }
+    }
+    V3<T> color, normal, view_dir;
+    if (live) {
+        color = ld3(material.color); // uv_color >= 2: no texture fetch (cuda.hpp:1850-1855)
+        color = elemul(color, vertex_color);
+        normal = raw_normal;
+        if (FIRST)
+            view_dir = neg(primary_ray_direction(sc, fb.win.W, fb.win.H, x, y));
+        else
+            view_dir = xyz(fb.view_direction[p]);
+        if (dot(view_dir, normal) < zero) {
+            if (material.double_sided)
+                normal = neg(normal);
+            else
+                live = false; // cuda.hpp:1873-1877
+        }
+    }
+    // Outputs are collected in registers and written by one unconditional store sequence at the end (see the
+    // note in k_fill_gbuffer about stores in both arms of a branch).
+    V4<T> o_intensity = zero4, o_albedo = zero4, o_mult = zero4, o_gidir = zero4, o_view = zero4;
+    uint2 o_skip = make_uint2(0xffffffffu, 0u);
+    uint32_t o_gi_valid = 0, mask = 0;
+    if (live) {
+        V3<T> bitangent = normalized(cross(raw_normal, raw_tangent));
+        V3<T> tangent = normalized(cross(bitangent, raw_normal));
+        o_skip = make_uint2(objectid, inobject_offset);
+        V3<T> emission = ld3(material.emission);
+        o_albedo = mk4(color.x, color.y, color.z, zero);
+
+        if (!NO_GI) {
+            Xorwow rs;
+            const uint32_t *st = fb.rng_state;
+            rs.v0 = st[p];
+            rs.v1 = st[npix + p];
+            rs.v2 = st[2 * npix + p];
+            rs.v3 = st[3 * npix + p];
+            rs.v4 = st[4 * npix + p];
+            rs.d = rng_d;
+            rs.bm_flag = 0;
+            rs.bm_extra = 0.f;
+            V3<T> dir, mult;
+            // NaN in .z tags "split lobes for demodulated SVGF" (cuda.hpp:1919)
+            const T nanT = cvt<T>(__builtin_nanf(""));
+            const T metallic = material.metallic, roughness = material.roughness;
+            if (roughness < cvt<T>(0.1f)) {
+                if (cvt<T>(xorwow_uniform(rs)) < metallic) {
+                    dir = normalized(reflect_about(view_dir, normal));
+                    mult = vdiv(get_brdf(glassy_brdf(metallic, view_dir, dir, normal), color), metallic);
+                } else if (cvt<T>(xorwow_uniform(rs)) < cvt<T>(0.6f)) {
+                    dir = normalized(reflect_about(view_dir, normal));
+                    Brdf<T> b = glassy_brdf(metallic, view_dir, dir, normal);
+                    T pdf = (one - metallic) * cvt<T>(0.6f);
+                    if (FIRST)
+                        mult = mk3(tdiv(b.colored, pdf), tdiv(b.white, pdf), nanT);
+                    else
+                        mult = vdiv(get_brdf(b, color), pdf);
+                } else { // Q10: uniform direction from three normals
+                    T n0 = cvt<T>(xorwow_normal(rs)), n1 = cvt<T>(xorwow_normal(rs)), n2 = cvt<T>(xorwow_normal(rs));
+                    V3<T> rd = normalized(mk3(n0, n1, n2));
+                    T cosine = dot(rd, normal);
+                    if (cosine < zero) {
+                        rd = neg(rd);
+                        cosine = tneg(cosine);
+                    }
+                    dir = rd;
+                    Brdf<T> b = material_brdf(metallic, roughness, view_dir, rd, normal);
+                    T m = cosine * cvt<T>((float)(LPRT_PI_D * 2));
+                    if (FIRST)
+                        mult = mk3(b.colored * m, b.white * m, nanT);
+                    else
+                        mult = get_brdf(b, color) * m;
+                }
+            } else {
+                T pdf, cosine;
+                V3<T> rd;
+                if (cvt<T>(xorwow_uniform(rs)) < metallic) {
+                    T a = roughness * roughness;
+                    T a2 = a * a;
+                    V3<T> ht = sample_ggx(a2, rs);
+                    pdf = pdf_ggx_reflect(ht.z, a2) * metallic;
+                    V3<T> hw = normalized(tangent * ht.x + bitangent * ht.y + normal * ht.z); // tangent_to_world (cuda.hpp:1737-1740)
+                    rd = reflect_about(view_dir, hw);
+                    cosine = tmax(cvt<T>(0.05f), dot(rd, hw));
+                    pdf = tdiv(pdf, cvt<T>(4.0f * (float)cosine)); // `4 * cosine`: int * DataT is formed in float
+                } else {
+                    rd.x = cvt<T>(xorwow_normal(rs));
+                    rd.y = cvt<T>(xorwow_normal(rs));
+                    rd.z = cvt<T>(xorwow_normal(rs));
+                    cosine = dot(rd, normal);
+                    if (cosine < zero) {
+                        rd = neg(rd);
+                        cosine = tneg(cosine);
+                    }
+                    pdf = cvt<T>((float)(0.5 / LPRT_PI_D)) * (one - metallic);
+                }
+                rd = normalized(rd);
+                dir = rd;
+                Brdf<T> b = material_brdf(metallic, roughness, view_dir, rd, normal);
+                T m = tdiv(cosine, pdf);
+                if (FIRST)
+                    mult = mk3(b.colored * m, b.white * m, nanT);
+                else
+                    mult = m * get_brdf(b, color);
+            }
+            o_gi_valid = 1;
+            o_gidir = mk4(dir.x, dir.y, dir.z, zero);
+            V3<T> nd = neg(dir);
+            o_view = mk4(nd.x, nd.y, nd.z, zero);
+            o_mult = mk4(mult.x, mult.y, mult.z, zero);
+            o_intensity = mk4(emission.x, emission.y, emission.z, zero);
+        } else {
+            // Q4: without GI the emission is overwritten by SKYBOX_COLOR (0) * color * 0.5 (cuda.hpp:2001-2006)
+            V3<T> sky = elemul(zero3<T>(), color) * cvt<T>(0.5f);
+            o_intensity = mk4(sky.x, sky.y, sky.z, zero);
+        }
+
+        // direct light commands (cuda.hpp:2009-2055)
+        const T rough_l = tmax(material.roughness, cvt<T>(0.10f));
+        for (uint32_t i = 0; i < LPRT_MAX_DIRECT_LIGHT; i++) {
+            if (i >= sc.n_lights)
+                break;
+            const LightT<T> light = sc.lights[i];
+            V3<T> light_dir, mm = zero3<T>();
+            T max_t = zero;
+            bool active = false;
+            if (light.type == LPRT_LIGHT_POINT || light.type == LPRT_LIGHT_SPOT) {
+                V3<T> ldv = ld3(light.position) - position;
+                light_dir = normalized(ldv);
+                T cosine = dot(light_dir, normal);
+                if (!(cosine < zero)) {
+                    T d2 = norm2_squared(ldv);
+                    V3<T> brdf = get_brdf(material_brdf(material.metallic, rough_l, view_dir, light_dir, normal), color);
+                    mm = tdiv(tdiv(cosine, d2), cvt<T>(10.f)) * elemul(brdf, ld3(light.intensity));
+                    max_t = tsqrt(d2);
+                    active = true;
+                }
+            } else {
+                light_dir = neg(normalized(ld3(light.direction)));
+                T cosine = dot(light_dir, normal);
+                if (!(cosine < zero)) {
+                    V3<T> brdf = get_brdf(material_brdf(material.metallic, rough_l, view_dir, light_dir, normal), color);
+                    mm = cosine * elemul(brdf, ld3(light.intensity));
+                    max_t = cvt<T>(1000.f);
+                    active = true;
+                }
+            }
+            if (active) {
+                mask |= 1u << i;
+                fb.lc_dir_maxt[i * npix + p] = mk4(light_dir.x, light_dir.y, light_dir.z, max_t);
+                fb.lc_multiplier[i * npix + p] = mk4(mm.x, mm.y, mm.z, zero);
+            }
+        }
+    }
+    fb.lc_mask[p] = (uint8_t)mask;
+    intensity[p] = o_intensity;
+    fb.skips[p] = o_skip;
+    if (FIRST) {
+        fb.albedo[p] = o_albedo;
+        fb.gi_valid[p] = (uint8_t)o_gi_valid; // DEVIATION Q13: untouched GI commands are invalid
+        fb.gi_multiplier[p] = o_mult;
+        fb.gi_direction[p] = o_gidir;
+        fb.view_direction[p] = o_view;
+    }
+}
+
+// ---- TD + A: trace_di_light + accumulate_di_light (cuda.hpp:2058-2081, 2143-2159) ------------------------------
+template <typename T, bool FIRST, bool COUNT>
+__global__ void __launch_bounds__(256) k_trace_di(SceneDev<T> sc, FrameDev<T> fb, Counters *counters) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t npix = fb.win.npix();
+    Cnt<COUNT> cnt;
+    if (p < npix) {
+        const uint32_t mask = fb.lc_mask[p];
+        if (mask) {
+            const T zero = (T)0, one = (T)1;
+            V4<T> *intensity = FIRST ? fb.intensity0 : fb.intensity1;
+            const V3<T> source = xyz(FIRST ? fb.g_position[p] : fb.sc_position[p]);
+            const uint2 skip = fb.skips[p];
+            V3<T> fc = zero3<T>(); // accumulate_di_light: final_color = {} ; += di_intensity[4p+i]
+            for (uint32_t i = 0; i < LPRT_MAX_DIRECT_LIGHT; i++) {
+                V3<T> di = zero3<T>();
+                if (mask & (1u << i)) {
+                    const V4<T> dm = fb.lc_dir_maxt[i * npix + p];
+                    const V3<T> mm = xyz(fb.lc_multiplier[i * npix + p]);
+                    RayT<T> ray{source, xyz(dm)};
+                    Isect<T> is = cast_ray<T, true, COUNT>(sc, ray, skip.x, skip.y, cvt<T>(ray_moveforward_t<T>()), dm.w, cnt);
+                    di = (is.hit ? zero : one) * mm;
+                }
+                fc = fc + di;
+            }
+            V4<T> cur = intensity[p];
+            intensity[p] = mk4(cur.x + fc.x, cur.y + fc.y, cur.z + fc.z, zero);
+        }
+    }
+    flush_counters<COUNT>(cnt, counters);
+}
+
+// ---- TG: trace_gi (cuda.hpp:2083-2141) ---------------------------------------------------------------------------
+template <typename T, bool COUNT>
+__global__ void __launch_bounds__(256) k_trace_gi(SceneDev<T> sc, FrameDev<T> fb, Counters *counters) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    Cnt<COUNT> cnt;
+    if (p < fb.win.npix()) {
+        uint32_t type = 0; // PixelShaderInput::INVALID
+        if (fb.gi_valid[p]) {
+            const uint2 skip = fb.skips[p];
+            RayT<T> ray{xyz(fb.g_position[p]), xyz(fb.gi_direction[p])};
+            Isect<T> is = cast_ray<T, false, COUNT>(sc, ray, skip.x, skip.y, cvt<T>(ray_moveforward_t<T>()), cvt<T>(1e5f), cnt);
+            if (is.hit) {
+                HitAttr<T> h = interpolate_hit(sc, is);
+                const T zero = (T)0;
+                fb.sc_normal[p] = mk4(h.normal.x, h.normal.y, h.normal.z, zero);
+                fb.sc_tangent[p] = mk4(h.tangent.x, h.tangent.y, h.tangent.z, zero);
+                fb.sc_position[p] = mk4(h.position.x, h.position.y, h.position.z, zero);
+                fb.sc_color[p] = mk4(h.color.x, h.color.y, h.color.z, zero);
+                fb.sc_uv[p] = mk4(h.uv0.x, h.uv0.y, h.uv1.x, h.uv1.y);
+                fb.sc_objid[p] = is.inscene_objid;
+                fb.sc_offset[p] = is.inobject_offset;
+                fb.sc_materialid[p] = sc.objects[is.inscene_objid].materialid;
+                type = 1; // COMMON
+            } else {
+                type = 2; // SKYBOX
+            }
+        }
+        fb.sc_type[p] = type;
+    }
+    flush_counters<COUNT>(cnt, counters);
+}
+
+// ---- write_clean_color (cuda.hpp:2170-2199) + the build-side spp mean --------------------------
+// sample s of n: accumulate in f32 in sample order; the last sample divides once and rounds once to DataT.
+template <typename T>
+__global__ void __launch_bounds__(256) k_compose(FrameDev<T> fb, int gi_on, int add_direct_out, uint32_t sample, uint32_t spp) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= fb.win.npix())
+        return;
+    const T zero = (T)0;
+    V3<T> fc = zero3<T>(), colored = zero3<T>(), white = zero3<T>();
+    const V4<T> m0 = fb.gi_multiplier[p];
+    if (add_direct_out)
+        fc = xyz(fb.intensity0[p]);
+    V3<T> i1 = gi_on ? xyz(fb.intensity1[p]) : zero3<T>();
+    if (tisnan(m0.z)) {
+        colored = m0.x * i1;
+        white = m0.y * i1;
+    } else if (add_direct_out) {
+        fc = fc + elemul(i1, xyz(m0));
+    }
+    float4 ac = make_float4((float)fc.x, (float)fc.y, (float)fc.z, 0.f);
+    float4 ag = make_float4((float)colored.x, (float)colored.y, (float)colored.z, 0.f);
+    float4 aw = make_float4((float)white.x, (float)white.y, (float)white.z, 0.f);
+    if (sample > 0) {
+        float4 o = fb.acc_color[p];
+        ac = make_float4(o.x + ac.x, o.y + ac.y, o.z + ac.z, 0.f);
+        o = fb.acc_gi_colored[p];
+        ag = make_float4(o.x + ag.x, o.y + ag.y, o.z + ag.z, 0.f);
+        o = fb.acc_gi_white[p];
+        aw = make_float4(o.x + aw.x, o.y + aw.y, o.z + aw.z, 0.f);
+    }
+    if (sample + 1 < spp) {
+        fb.acc_color[p] = ac;
+        fb.acc_gi_colored[p] = ag;
+        fb.acc_gi_white[p] = aw;
+    } else {
+        const float n = (float)spp;
+        V4<T> c = mk4(cvt<T>(ac.x / n), cvt<T>(ac.y / n), cvt<T>(ac.z / n), zero);
+        V4<T> g = mk4(cvt<T>(ag.x / n), cvt<T>(ag.y / n), cvt<T>(ag.z / n), zero);
+        V4<T> w = mk4(cvt<T>(aw.x / n), cvt<T>(aw.y / n), cvt<T>(aw.z / n), zero);
+        fb.color_inprogress[p] = c;
+        fb.lobe[0].cv_a[p] = g;
+        fb.lobe[1].cv_a[p] = w;
+        fb.raw_color[p] = c;
+        fb.raw_gi_colored[p] = g;
+        fb.raw_gi_white[p] = w;
+    }
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------------------
+static inline dim3 grid_for(uint32_t n) { return dim3((n + 255) / 256); }
+
+template <typename T> void launch_fill_gbuffer(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, Counters *c) {
+    if (c)
+        hipLaunchKernelGGL((k_fill_gbuffer<T, true>), grid_for(fb.win.npix()), dim3(256), 0, st, sc, fb, c);
+    else
+        hipLaunchKernelGGL((k_fill_gbuffer<T, false>), grid_for(fb.win.npix()), dim3(256), 0, st, sc, fb, c);
+}
+template <typename T> void launch_temporal_map(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, uint32_t rng_d) {
+    hipLaunchKernelGGL(k_temporal_map<T>, grid_for(fb.win.npix()), dim3(256), 0, st, sc, fb, first ? 1 : 0, rng_d);
+}
+template <typename T> void launch_shade(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, bool no_gi, uint32_t rng_d) {
+    dim3 g = grid_for(fb.win.npix()), b(256);
+    if (first && !no_gi)
+        hipLaunchKernelGGL((k_shade<T, true, false>), g, b, 0, st, sc, fb, rng_d);
+    else if (first)
+        hipLaunchKernelGGL((k_shade<T, true, true>), g, b, 0, st, sc, fb, rng_d);
+    else
+        hipLaunchKernelGGL((k_shade<T, false, true>), g, b, 0, st, sc, fb, rng_d);
+}
+template <typename T> void launch_trace_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, Counters *c) {
+    dim3 g = grid_for(fb.win.npix()), b(256);
+    if (first) {
+        if (c)
+            hipLaunchKernelGGL((k_trace_di<T, true, true>), g, b, 0, st, sc, fb, c);
+        else
+            hipLaunchKernelGGL((k_trace_di<T, true, false>), g, b, 0, st, sc, fb, c);
+    } else {
+        if (c)
+            hipLaunchKernelGGL((k_trace_di<T, false, true>), g, b, 0, st, sc, fb, c);
+        else
+            hipLaunchKernelGGL((k_trace_di<T, false, false>), g, b, 0, st, sc, fb, c);
+    }
+}
+template <typename T> void launch_trace_gi(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, Counters *c) {
+    if (c)
+        hipLaunchKernelGGL((k_trace_gi<T, true>), grid_for(fb.win.npix()), dim3(256), 0, st, sc, fb, c);
+    else
+        hipLaunchKernelGGL((k_trace_gi<T, false>), grid_for(fb.win.npix()), dim3(256), 0, st, sc, fb, c);
+}
+template <typename T> void launch_compose(hipStream_t st, const FrameDev<T> &fb, bool gi_on, bool add_direct, uint32_t sample, uint32_t spp) {
+    hipLaunchKernelGGL(k_compose<T>, grid_for(fb.win.npix()), dim3(256), 0, st, fb, gi_on ? 1 : 0, add_direct ? 1 : 0, sample, spp);
+}
+
+#define INST(T)                                                                                                        \
+    template void launch_fill_gbuffer<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, Counters *);          \
+    template void launch_temporal_map<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, uint32_t);      \
+    template void launch_shade<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, bool, uint32_t);       \
+    template void launch_trace_di<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, Counters *);        \
+    template void launch_trace_gi<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, Counters *);              \
+    template void launch_compose<T>(hipStream_t, const FrameDev<T> &, bool, bool, uint32_t, uint32_t);
+INST(float)
+INST(h16)
+#undef INST
+
+} // namespace lprt

@@ -1,0 +1,190 @@
+// curand_init(seed, subsequence = pixel index, offset = 0) for every pixel of the window, without the
+// per-thread skip-ahead the reference pays in every shade launch (rt/rtrt/cuda.hpp:1763-1764, 2353-2354).
+//
+// XORWOW's xorshift state v (160 bits) evolves linearly over GF(2); one subsequence = 2^67 steps = one fixed
+// 160x160 matrix M, so state(n) = M^n * v0(seed).  (The Weyl counter d is untouched: 2^67 * 362437 = 0 mod 2^32.)
+// Writing n in base 64, n = 64^3*j3 + 64^2*j2 + 64*j1 + j0:
+//     state(n) = M^j0 * (M64^j1 * (M4096^j2 * W3[j3])),   W3[j3] = M^(64^3 * j3) * v0   (a handful, on the host)
+// Every level is the same kernel: dst[s*64 + j] = P_level[j] * src[s], with the 64 matrices P_level[j] FIXED
+// (seed independent, 3 x 64 x 5 KB in HBM, L2 resident) and j WAVE-UNIFORM, so the matrix streams through
+// scalar loads while the 64 lanes hold 64 different source vectors: one matvec per pixel, ~1.8k VALU ops,
+// instead of ~16 dependent matvecs with per-lane matrices.
+#include "kernels.hpp"
+#include <mutex>
+
+namespace lprt {
+
+// matrix image in HBM: column i (image of basis vector e_i) padded to 8 words -> one 32-B scalar load
+struct XorMat {
+    uint32_t col[160][8];
+};
+
+// dst[(s*64 + j) - dst_first] = P[j] * src[s].  One block = 64 consecutive s x 16 consecutive j; a wave owns 4 j.
+__global__ void __launch_bounds__(256) k_rng_expand(const XorMat *__restrict__ P, const uint32_t *__restrict__ src, uint32_t n_src, uint32_t src_stride,
+                                                    uint32_t *__restrict__ dst, uint32_t dst_first, uint32_t dst_count, uint32_t dst_stride) {
+    __shared__ uint32_t tile[5][64][17];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t s = blockIdx.x * 64 + lane;
+    const uint32_t jbase = blockIdx.y * 16;
+    uint32_t v[5] = {0, 0, 0, 0, 0};
+    if (s < n_src)
+        for (int k = 0; k < 5; k++)
+            v[k] = src[k * src_stride + s];
+    for (uint32_t jj = 0; jj < 4; jj++) {
+        const uint32_t jl = wave * 4 + jj; // 0..15 within the block
+        const uint32_t j = __builtin_amdgcn_readfirstlane(jbase + jl);
+        const XorMat *m = P + j;
+        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+#pragma unroll
+        for (int w = 0; w < 5; w++) {
+            const uint32_t bits = v[w];
+#pragma unroll 8
+            for (int b = 0; b < 32; b++) {
+                const uint32_t *c = m->col[w * 32 + b];
+                const uint32_t mask = (uint32_t)__builtin_amdgcn_sbfe((int)bits, b, 1); // 0 or ~0
+                a0 ^= c[0] & mask;
+                a1 ^= c[1] & mask;
+                a2 ^= c[2] & mask;
+                a3 ^= c[3] & mask;
+                a4 ^= c[4] & mask;
+            }
+        }
+        tile[0][lane][jl] = a0;
+        tile[1][lane][jl] = a1;
+        tile[2][lane][jl] = a2;
+        tile[3][lane][jl] = a3;
+        tile[4][lane][jl] = a4;
+    }
+    __syncthreads();
+    // coalesced write-out: for each of the 64 sources, 16 consecutive destinations
+    for (uint32_t e = threadIdx.x; e < 64 * 16; e += 256) {
+        const uint32_t sl = e >> 4, jl = e & 15;
+        const uint32_t ss = blockIdx.x * 64 + sl;
+        if (ss >= n_src)
+            continue;
+        const uint32_t n = ss * 64 + jbase + jl;
+        if (n < dst_first || n - dst_first >= dst_count)
+            continue;
+        for (int k = 0; k < 5; k++)
+            dst[k * dst_stride + (n - dst_first)] = tile[k][sl][jl];
+    }
+}
+
+// ---- host-side GF(2) algebra for the fixed matrices ---------------------------------------------------------------------
+namespace {
+struct HMat {
+    uint32_t col[160][5];
+};
+inline void h_apply(const HMat &m, const uint32_t in[5], uint32_t out[5]) {
+    uint32_t r[5] = {0, 0, 0, 0, 0};
+    for (int w = 0; w < 5; w++) {
+        uint32_t bits = in[w];
+        while (bits) {
+            int b = __builtin_ctz(bits);
+            bits &= bits - 1;
+            const uint32_t *c = m.col[w * 32 + b];
+            r[0] ^= c[0]; r[1] ^= c[1]; r[2] ^= c[2]; r[3] ^= c[3]; r[4] ^= c[4];
+        }
+    }
+    for (int k = 0; k < 5; k++)
+        out[k] = r[k];
+}
+inline HMat h_mul(const HMat &a, const HMat &b) { // apply b first, then a
+    HMat c;
+    for (int i = 0; i < 160; i++)
+        h_apply(a, b.col[i], c.col[i]);
+    return c;
+}
+inline HMat h_identity() {
+    HMat m{};
+    for (int i = 0; i < 160; i++)
+        m.col[i][i / 32] = 1u << (i % 32);
+    return m;
+}
+struct Tables {
+    std::vector<XorMat> levels; // [3][64]
+    HMat m_top;                 // M^(64^3)
+};
+const Tables &tables() {
+    static Tables t;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // one xorwow step as a matrix
+        HMat a{};
+        for (int i = 0; i < 160; i++) {
+            uint32_t v[5] = {0, 0, 0, 0, 0};
+            v[i / 32] = 1u << (i % 32);
+            uint32_t tt = v[0] ^ (v[0] >> 2);
+            uint32_t n4 = (v[4] ^ (v[4] << 4)) ^ (tt ^ (tt << 1));
+            a.col[i][0] = v[1];
+            a.col[i][1] = v[2];
+            a.col[i][2] = v[3];
+            a.col[i][3] = v[4];
+            a.col[i][4] = n4;
+        }
+        for (int i = 0; i < 67; i++)
+            a = h_mul(a, a); // M = A^(2^67)
+        t.levels.resize(3 * 64);
+        HMat base = a;
+        for (int level = 0; level < 3; level++) {
+            HMat p = h_identity();
+            for (int j = 0; j < 64; j++) {
+                XorMat &x = t.levels[level * 64 + j];
+                for (int i = 0; i < 160; i++) {
+                    for (int k = 0; k < 5; k++)
+                        x.col[i][k] = p.col[i][k];
+                    x.col[i][5] = x.col[i][6] = x.col[i][7] = 0;
+                }
+                p = h_mul(base, p);
+            }
+            base = p; // base^64
+        }
+        t.m_top = base;
+    });
+    return t;
+}
+} // namespace
+
+void RngStore::init(hipStream_t st) {
+    const Tables &t = tables();
+    d_mats.reserve(sizeof(XorMat) * t.levels.size());
+    LPRT_HIP(hipMemcpyAsync(d_mats.ptr, t.levels.data(), sizeof(XorMat) * t.levels.size(), hipMemcpyHostToDevice, st));
+    LPRT_HIP(hipStreamSynchronize(st));
+    ready = true;
+}
+
+// fills `planes` ([5][count], plane stride = count) with the states of pixels [first, first+count); returns d(seed)
+uint32_t RngStore::generate(hipStream_t st, uint64_t seed, uint32_t total_pixels, uint32_t first, uint32_t count, uint32_t *planes) {
+    // curand_init seed scramble
+    uint32_t s0 = (uint32_t)seed ^ 0xaad26b49u, s1 = (uint32_t)(seed >> 32) ^ 0xf7dcefddu;
+    uint32_t t0 = 1099087573u * s0, t1 = 2591861531u * s1;
+    uint32_t d = 6615241u + t1 + t0;
+    uint32_t v[5] = {123456789u + t0, 362436069u ^ t0, 521288629u + t1, 88675123u ^ t1, 5783321u + t0};
+    const Tables &t = tables();
+    const uint32_t n1 = (total_pixels + 63) / 64, n2 = (n1 + 63) / 64, n3 = (n2 + 63) / 64;
+    // level-3 vectors on the host, SoA [5][n3]
+    std::vector<uint32_t> w3(5 * (size_t)n3);
+    for (uint32_t j = 0; j < n3; j++) {
+        for (int k = 0; k < 5; k++)
+            w3[k * n3 + j] = v[k];
+        h_apply(t.m_top, v, v);
+    }
+    d_w3.reserve(sizeof(uint32_t) * w3.size());
+    d_w2.reserve(sizeof(uint32_t) * 5 * (size_t)n3 * 64);
+    d_w1.reserve(sizeof(uint32_t) * 5 * (size_t)n2 * 64);
+    LPRT_HIP(hipMemcpyAsync(d_w3.ptr, w3.data(), sizeof(uint32_t) * w3.size(), hipMemcpyHostToDevice, st));
+    LPRT_HIP(hipStreamSynchronize(st)); // w3 is a stack-lifetime staging buffer
+    const XorMat *mats = d_mats.as<XorMat>();
+    hipLaunchKernelGGL(k_rng_expand, dim3((n3 + 63) / 64, 4), dim3(256), 0, st, mats + 128, d_w3.as<uint32_t>(), n3, n3, d_w2.as<uint32_t>(), 0u,
+                       n3 * 64, n3 * 64);
+    hipLaunchKernelGGL(k_rng_expand, dim3((n2 + 63) / 64, 4), dim3(256), 0, st, mats + 64, d_w2.as<uint32_t>(), n2, n3 * 64, d_w1.as<uint32_t>(), 0u,
+                       n2 * 64, n2 * 64);
+    // last level only for the L1 vectors that cover [first, first + count)
+    const uint32_t s_begin = first / 64, s_end = (first + count + 63) / 64;
+    hipLaunchKernelGGL(k_rng_expand, dim3((s_end - s_begin + 63) / 64, 4), dim3(256), 0, st, mats, d_w1.as<uint32_t>() + s_begin, s_end - s_begin,
+                       n2 * 64, planes, first - s_begin * 64, count, count);
+    LPRT_HIP(hipGetLastError());
+    return d;
+}
+
+} // namespace lprt

@@ -1,0 +1,141 @@
+// Device BRDFs, importance sampling and the cuRAND-compatible XORWOW stepping used by shade().
+// Restates rt/rtrt/bsdf.hpp:12-139 and rt/rtrt/cuda.hpp:1713-1749 with explicit rounding points.
+#pragma once
+#include "types.hpp"
+
+namespace lprt {
+
+#define LPRT_PI_D 3.14159265358979323846
+
+// ---- XORWOW (cuRAND device API; third party, restated from its published algorithm) -------------------
+struct Xorwow {
+    uint32_t v0, v1, v2, v3, v4, d;
+    int bm_flag;
+    float bm_extra;
+};
+LPRT_DEV uint32_t xorwow_next(Xorwow &s) {
+    uint32_t t = s.v0 ^ (s.v0 >> 2);
+    s.v0 = s.v1;
+    s.v1 = s.v2;
+    s.v2 = s.v3;
+    s.v3 = s.v4;
+    s.v4 = (s.v4 ^ (s.v4 << 4)) ^ (t ^ (t << 1));
+    s.d += 362437u;
+    return s.v4 + s.d;
+}
+LPRT_DEV float xorwow_uniform(Xorwow &s) { // curand_uniform: (0, 1]
+    return (float)xorwow_next(s) * 2.3283064e-10f + (2.3283064e-10f / 2.0f);
+}
+LPRT_DEV float xorwow_normal(Xorwow &s) { // curand_normal: Box-Muller pair, second value cached
+    if (s.bm_flag) {
+        s.bm_flag = 0;
+        return s.bm_extra;
+    }
+    uint32_t x = xorwow_next(s), y = xorwow_next(s);
+    float u = (float)x * 2.3283064e-10f + (2.3283064e-10f / 2.0f);
+    float v = (float)y * 1.46291807e-09f + (1.46291807e-09f / 2.0f);
+    float r = __builtin_sqrtf(-2.0f * ::logf(u));
+    s.bm_extra = r * ::cosf(v);
+    s.bm_flag = 1;
+    return r * ::sinf(v);
+}
+
+// ---- BRDF (bsdf.hpp) -----------------------------------------------------------------------------------
+template <typename T> struct Brdf {
+    T colored, white;
+};
+template <typename T> LPRT_DEV V3<T> get_brdf(Brdf<T> b, V3<T> base) { // bsdf.hpp:52-54
+    V3<T> one = mk3((T)1, (T)1, (T)1);
+    return base * b.colored + one * b.white;
+}
+template <typename T> LPRT_DEV T specular_brdf(V3<T> V, V3<T> H, V3<T> L, V3<T> N, T alpha) { // bsdf.hpp:12-33
+    T HdotL = dot(H, L), HdotV = dot(H, V), NdotH = dot(N, H);
+    T zero = (T)0;
+    if (NdotH <= zero || HdotL <= zero || HdotV <= zero)
+        return zero;
+    T aNL = tabs(dot(N, L)), aNV = tabs(dot(N, V));
+    T a2 = alpha * alpha;
+    T one = (T)1;
+    T div1 = aNL + tsqrt(tmax(zero, a2 + (one - a2) * aNL * aNL));
+    T div2 = aNV + tsqrt(tmax(zero, a2 + (one - a2) * aNV * aNV));
+    T D = tdiv(a2, cvt<T>((float)LPRT_PI_D) * tpow(NdotH * NdotH * (a2 - one) + one, (T)2));
+    return tdiv(tdiv(D, div1), div2);
+}
+template <typename T> LPRT_DEV T fresnel_pow5(V3<T> V, V3<T> H) {
+    T VdotH = dot(V, H);
+    return tpow(tmax((T)0, (T)1 - tabs(VdotH)), (T)5);
+}
+template <typename T> LPRT_DEV Brdf<T> material_brdf(T metallic, T roughness, V3<T> V, V3<T> L, V3<T> N) { // bsdf.hpp:57-97
+    T zero = (T)0, one = (T)1;
+    if (dot(L, N) < zero)
+        return {zero, zero};
+    V3<T> H = normalized(L + V);
+    T pow5 = fresnel_pow5(V, H);
+    T alpha = roughness * roughness;
+    T layer = specular_brdf(V, H, L, N, alpha);
+    T f0 = cvt<T>(0.04f);
+    T fr = f0 + cvt<T>(1.0f - (float)f0) * pow5; // DataT(1 - dielectric_f0): formed in float
+    T dielectric_white = fr * layer;
+    T dielectric_colored = (one - fr) * cvt<T>((float)(1.0 / LPRT_PI_D));
+    T metal_white = layer * pow5;
+    T metal_colored = layer * (one - pow5);
+    return {metal_colored * metallic + dielectric_colored * (one - metallic),
+            metal_white * metallic + dielectric_white * (one - metallic)};
+}
+template <typename T> LPRT_DEV Brdf<T> glassy_brdf(T metallic, V3<T> V, V3<T> L, V3<T> N) { // bsdf.hpp:106-139
+    T zero = (T)0, one = (T)1;
+    if (dot(L, N) < zero)
+        return {zero, zero};
+    V3<T> H = normalized(L + V);
+    T pow5 = fresnel_pow5(V, H);
+    T f0 = cvt<T>(0.04f);
+    T fr = f0 + cvt<T>(1.0f - (float)f0) * pow5;
+    T metal_colored = one - pow5;
+    return {metal_colored * metallic + zero * (one - metallic), pow5 * metallic + fr * (one - metallic)};
+}
+
+// ---- sampling (cuda.hpp:1714-1734) -----------------------------------------------------------------------
+template <typename T> LPRT_DEV V3<T> sample_ggx(T a2, Xorwow &st) { // Q9: x, y are r*u2, r*u3
+    T rx = cvt<T>(xorwow_uniform(st)), ry = cvt<T>(xorwow_uniform(st)), rz = cvt<T>(xorwow_uniform(st));
+    T one = (T)1;
+    T z = tsqrt(tdiv(one - rx, one + a2 * rx - rx));
+    T r = tsqrt(tmax((T)0, one - z * z));
+    return mk3(r * ry, r * rz, z);
+}
+template <typename T> LPRT_DEV T pdf_ggx_reflect(T NH, T a2) {
+    T tmp = (NH * a2 - NH) * NH + (T)1;
+    // D_ggx_opti returns `M_PI * tmp * tmp`: double arithmetic, then double -> float -> DataT
+    T D = cvt<T>((float)(LPRT_PI_D * (double)(float)tmp * (double)(float)tmp));
+    return tdiv(NH * a2, D);
+}
+
+// ---- camera (CUDARenderGISettings, cuda.hpp:799-832) ---------------------------------------------------------
+template <typename T> LPRT_DEV void primary_xy(const SceneDev<T> &sc, uint32_t W, uint32_t H, uint32_t sx, uint32_t sy, T &x, T &y) {
+    T fx = cvt<T>((float)sx), fy = cvt<T>((float)sy), fw = cvt<T>((float)W), fh = cvt<T>((float)H);
+    T two = (T)2, one = (T)1, half_ = cvt<T>(0.5f);
+    T nx = tdiv(two * (fx + half_), fw) - one;
+    T ny = tdiv(two * (fy + half_), fh) - one;
+    T max_y = ttan(tdiv(sc.cam_fovy, two));
+    y = ny * max_y;
+    x = tdiv(nx * max_y * fw, fh); // omit_ar = true
+}
+template <typename T> LPRT_DEV RayT<T> primary_ray(const SceneDev<T> &sc, uint32_t W, uint32_t H, uint32_t sx, uint32_t sy) {
+    T x, y;
+    primary_xy(sc, W, H, sx, sy, x, y);
+    RayT<T> r;
+    r.o = zero3<T>();
+    r.d = normalized(mk3(x, y, (T)(-1)));
+    // ray.transformed(L2W) then direction.normalize()
+    V3<T> o = xform_pos(sc.cam_L2W, r.o);
+    V3<T> d = xform_dir(sc.cam_L2W, r.d);
+    r.o = o;
+    r.d = normalized(d);
+    return r;
+}
+template <typename T> LPRT_DEV V3<T> primary_ray_direction(const SceneDev<T> &sc, uint32_t W, uint32_t H, uint32_t sx, uint32_t sy) {
+    T x, y;
+    primary_xy(sc, W, H, sx, sy, x, y);
+    return normalized(xform_dir(sc.cam_L2W, mk3(x, y, (T)(-1))));
+}
+
+} // namespace lprt

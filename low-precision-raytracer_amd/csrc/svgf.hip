@@ -1,0 +1,388 @@
+// SVGF temporal/spatial denoiser, TAA, output and temporal back-up kernels.
+//
+// Replaces preprocess_normal_depth, temporal_accumulation_color, temporal_accumulation_moments,
+// wavelet_filter<stride>, svgf_denoise (rt/rtrt/cuda.hpp:1187-1473, 1636-1711), add_denoised_color,
+// temporal_anti_aliasing, write_to_surface2d, copy_last_frame_pixel_id/transform (cuda.hpp:2201-2263,
+// 2418-2455).  Formulas: SURVEY.md Appendix C.
+//
+// The reference runs svgf_denoise twice per frame (colored / white lobe, imgui_window.cu:232-238),
+// recomputing identical normal/depth planes and identical geometric weights.  Here both lobes are
+// filtered by the same thread: w_z, w_n and h are evaluated once per tap and shared; only w_l differs.
+// Colour and variance of a lobe travel as one {r,g,b,var} vector (one load per tap).
+#include "kernels.hpp"
+#include "shade.hpp"
+
+namespace lprt {
+
+template <typename T> struct SvgfConst {
+    static LPRT_DEV T eps() { return cvt<T>(1e-5f); } // a half subnormal (cuda.hpp:1261)
+};
+
+// sample_linear (cuda.hpp:1085-1115) on a 4-vector plane: xyz blended, result / sum via the rounded reciprocal
+template <typename T> LPRT_DEV V3<T> sample_linear3(const TemporalMapT<T> &m, const V4<T> *arr, uint32_t W, V3<T> dflt) {
+    if (m.frame_count == 0)
+        return dflt;
+    T sum = (T)0;
+    V3<T> r = zero3<T>();
+    for (int i = 0; i < 4; i++) {
+        T w = m.weights[i];
+        if (w == (T)0)
+            continue;
+        sum = sum + w;
+        r = r + w * xyz(arr[(uint32_t)m.pos[i][1] * W + m.pos[i][0]]);
+    }
+    return vdiv(r, sum);
+}
+template <typename T> LPRT_DEV T sample_linear1(const TemporalMapT<T> &m, const T *arr, uint32_t W, T dflt) {
+    if (m.frame_count == 0)
+        return dflt;
+    T sum = (T)0, r = (T)0;
+    for (int i = 0; i < 4; i++) {
+        T w = m.weights[i];
+        if (w == (T)0)
+            continue;
+        sum = sum + w;
+        r = r + w * arr[(uint32_t)m.pos[i][1] * W + m.pos[i][0]];
+    }
+    return tdiv(r, sum); // scalar: a true division
+}
+
+// ---- preprocess_normal_depth (cuda.hpp:1442-1473): only the gradient needs a plane of its own ---------------
+template <typename T> __global__ void __launch_bounds__(256) k_depth_gradient(FrameDev<T> fb) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= fb.win.npix())
+        return;
+    const uint32_t W = fb.win.W, x = p % W, ly = p / W;
+    const T dp = fb.g_normal_depth[p].w;
+    V2<T> g;
+    g.x = (x == 0) ? fb.g_normal_depth[p + 1].w - dp : dp - fb.g_normal_depth[p - 1].w;
+    g.y = (ly == 0) ? fb.g_normal_depth[p + W].w - dp : dp - fb.g_normal_depth[p - W].w;
+    fb.depth_gradient[p] = g;
+}
+
+// ---- temporal_accumulation_color (cuda.hpp:1187-1243), both lobes -------------------------------------------------
+// Reads the lobe's cv_a (this frame) and cv_b (history), writes cv_c.rgb and illum: out of place, so the 9x9
+// window always sees this frame's unmodified input (the reference updates in place and races).
+template <typename T>
+__global__ void __launch_bounds__(256) k_temporal_color(FrameDev<T> fb, T color_w) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= fb.win.npix())
+        return;
+    const int W = (int)fb.win.W, R = (int)fb.win.rows();
+    const int px = (int)(p % fb.win.W), py = (int)(p / fb.win.W);
+    const TemporalMapT<T> ti = fb.svgf_map[p];
+    const T zero = (T)0, one = (T)1, half_ = cvt<T>(0.5f);
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+        const V4<T> *in = fb.lobe[l].cv_a;
+        V3<T> pc = xyz(in[p]);
+        V3<T> m1 = zero3<T>(), m2 = zero3<T>(), wt = zero3<T>();
+        for (int i = -4; i <= 4; i++) {
+            int qx = px + i;
+            if (qx < 0 || qx >= W)
+                continue;
+            for (int j = -4; j <= 4; j++) {
+                int qy = py + j;
+                if (qy < 0 || qy >= R)
+                    continue;
+                V4<T> q = in[qy * W + qx];
+                if (tfinite(q.x)) { wt.x = wt.x + one; m1.x = m1.x + q.x; m2.x = m2.x + q.x * q.x; }
+                if (tfinite(q.y)) { wt.y = wt.y + one; m1.y = m1.y + q.y; m2.y = m2.y + q.y * q.y; }
+                if (tfinite(q.z)) { wt.z = wt.z + one; m1.z = m1.z + q.z; m2.z = m2.z + q.z * q.z; }
+            }
+        }
+        m1 = elediv(m1, wt);
+        m2 = elediv(m2, wt);
+        value_or(pc, m1);
+        V3<T> var = m2 - elemul(m1, m1);
+        T sx = tsqrt(var.x), sy = tsqrt(var.y), sz = tsqrt(var.z);
+        pc.x = clip_both(m1.x - half_ * sx, m1.x + half_ * sx, pc.x);
+        pc.y = clip_both(m1.y - half_ * sy, m1.y + half_ * sy, pc.y);
+        pc.z = clip_both(m1.z - half_ * sz, m1.z + half_ * sz, pc.z);
+        V3<T> hist = sample_linear3(ti, fb.lobe[l].cv_b, fb.win.W, pc);
+        value_or(hist, pc);
+        V3<T> out = color_w * pc + (one - color_w) * hist;
+        T illum = cvt<T>(0.2126f) * out.x + cvt<T>(0.7152f) * out.y + cvt<T>(0.0722f) * out.z;
+        fb.lobe[l].cv_c[p] = mk4(out.x, out.y, out.z, zero);
+        fb.lobe[l].illum[p] = illum;
+    }
+}
+
+// geometric part of a tap's weight, shared by both lobes: h * w_z * w_n is NOT pre-multiplied because the
+// reference multiplies w_z * w_n (* w_l) first and h last
+template <typename T> LPRT_DEV void geo_weights(T depth_p, T depth_q, V2<T> grad, T dx, T dy, V3<T> n_p, V3<T> n_q, T &w_z, T &w_n) {
+    // exp(-abs(dz) / (SIGMA_Z * abs(dot(grad, dp) + EPS))): the unary minus makes the quotient a float
+    float num = -(float)tabs(depth_p - depth_q);
+    float den = (float)((T)1 * tabs(dot(grad, V2<T>{dx, dy}) + SvgfConst<T>::eps()));
+    w_z = cvt<T>(::expf(num / den));
+    w_n = tpow(tmax((T)0, dot(n_p, n_q)), cvt<T>(128.f));
+}
+
+// ---- temporal_accumulation_moments (cuda.hpp:1245-1337), both lobes ---------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) k_moments(FrameDev<T> fb, T moments_w) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= fb.win.npix())
+        return;
+    const int W = (int)fb.win.W, R = (int)fb.win.rows();
+    const int px = (int)(p % fb.win.W), py = (int)(p / fb.win.W);
+    const TemporalMapT<T> ti = fb.svgf_map[p];
+    const T zero = (T)0, one = (T)1;
+    const T hk[3] = {cvt<T>(0.375f), cvt<T>(0.25f), cvt<T>(0.0625f)};
+    T illum[2] = {fb.lobe[0].illum[p], fb.lobe[1].illum[p]};
+    T miu1[2] = {zero, zero}, miu2[2] = {zero, zero};
+    if (ti.frame_count < 4) {
+        const V4<T> nd_p = fb.g_normal_depth[p];
+        const V2<T> grad = fb.depth_gradient[p];
+        T weight[2] = {zero, zero};
+        for (int i = -2; i <= 2; i++) {
+            int qx = px + i;
+            if (qx < 0 || qx >= W)
+                continue;
+            for (int j = -2; j <= 2; j++) {
+                int qy = py + j;
+                if (qy < 0 || qy >= R)
+                    continue;
+                uint32_t q = (uint32_t)(qy * W + qx);
+                T h = hk[i < 0 ? -i : i] * hk[j < 0 ? -j : j];
+                const V4<T> nd_q = fb.g_normal_depth[q];
+                T w_z, w_n;
+                geo_weights(nd_p.w, nd_q.w, grad, cvt<T>((float)i), cvt<T>((float)j), xyz(nd_p), xyz(nd_q), w_z, w_n);
+                T hw = h * (w_z * w_n);
+                if (tfinite(hw)) {
+#pragma unroll
+                    for (int l = 0; l < 2; l++) {
+                        T iq = fb.lobe[l].illum[q];
+                        if (tfinite(iq)) {
+                            miu1[l] = miu1[l] + hw * iq;
+                            miu2[l] = miu2[l] + hw * iq * iq;
+                            weight[l] = weight[l] + hw;
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < 2; l++) {
+            miu1[l] = tdiv(miu1[l], weight[l]);
+            miu2[l] = tdiv(miu2[l], weight[l]);
+        }
+    } else {
+#pragma unroll
+        for (int l = 0; l < 2; l++) {
+            T i2 = illum[l] * illum[l];
+            miu1[l] = (one - moments_w) * sample_linear1(ti, fb.lobe[l].miu1_hist, fb.win.W, miu1[l]) + illum[l] * moments_w;
+            miu2[l] = (one - moments_w) * sample_linear1(ti, fb.lobe[l].miu2_hist, fb.win.W, miu2[l]) + i2 * moments_w;
+            if (!tfinite(miu1[l]))
+                miu1[l] = illum[l];
+            if (!tfinite(miu2[l]))
+                miu2[l] = i2;
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+        fb.lobe[l].miu1_cur[p] = miu1[l];
+        fb.lobe[l].miu2_cur[p] = miu2[l];
+        fb.lobe[l].cv_c[p].w = miu2[l] - miu1[l] * miu1[l]; // variance, not clamped at 0
+    }
+}
+
+// ---- wavelet_filter<stride> (cuda.hpp:1339-1440), both lobes ---------------------------------------------------------------
+template <typename T, int STRIDE>
+__global__ void __launch_bounds__(256) k_wavelet(FrameDev<T> fb, const V4<T> *in0, V4<T> *out0, const V4<T> *in1, V4<T> *out1) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= fb.win.npix())
+        return;
+    const int W = (int)fb.win.W, R = (int)fb.win.rows();
+    const int px = (int)(p % fb.win.W), py = (int)(p / fb.win.W);
+    const T zero = (T)0;
+    const T hk[3] = {cvt<T>(0.375f), cvt<T>(0.25f), cvt<T>(0.0625f)};
+    const T gk[2] = {cvt<T>(0.5f), cvt<T>(0.25f)};
+    const V4<T> *in[2] = {in0, in1};
+    V4<T> *out[2] = {out0, out1};
+    // 1. 3x3 gaussian of the variance -> sigma_l
+    T sg[2] = {zero, zero};
+    T gw = zero;
+    for (int i = -1; i <= 1; i++) {
+        int qx = px + i;
+        if (qx < 0 || qx >= W)
+            continue;
+        for (int j = -1; j <= 1; j++) {
+            int qy = py + j;
+            if (qy < 0 || qy >= R)
+                continue;
+            T g = gk[i < 0 ? -i : i] * gk[j < 0 ? -j : j];
+            uint32_t q = (uint32_t)(qy * W + qx);
+            sg[0] = sg[0] + g * in[0][q].w;
+            sg[1] = sg[1] + g * in[1][q].w;
+            gw = gw + g;
+        }
+    }
+    sg[0] = tsqrt(tdiv(sg[0], gw));
+    sg[1] = tsqrt(tdiv(sg[1], gw));
+    // 2. 5x5 a-trous taps
+    const V4<T> nd_p = fb.g_normal_depth[p];
+    const V2<T> grad = fb.depth_gradient[p];
+    const T illum_p[2] = {fb.lobe[0].illum[p], fb.lobe[1].illum[p]};
+    T nvar[2] = {zero, zero}, wv[2] = {zero, zero}, wc[2] = {zero, zero};
+    V3<T> ncol[2] = {zero3<T>(), zero3<T>()};
+    for (int i = -2; i <= 2; i++) {
+        int qx = px + STRIDE * i;
+        if (qx < 0 || qx >= W)
+            continue;
+        for (int j = -2; j <= 2; j++) {
+            int qy = py + STRIDE * j;
+            if (qy < 0 || qy >= R)
+                continue;
+            uint32_t q = (uint32_t)(qy * W + qx);
+            T h = hk[i < 0 ? -i : i] * hk[j < 0 ? -j : j];
+            const V4<T> nd_q = fb.g_normal_depth[q];
+            T w_z, w_n;
+            geo_weights(nd_p.w, nd_q.w, grad, cvt<T>((float)(STRIDE * i)), cvt<T>((float)(STRIDE * j)), xyz(nd_p), xyz(nd_q), w_z, w_n);
+            T wzn = w_z * w_n;
+#pragma unroll
+            for (int l = 0; l < 2; l++) {
+                T iq = fb.lobe[l].illum[q];
+                float num = -(float)tabs(illum_p[l] - iq);
+                float den = (float)(cvt<T>(4.f) * sg[l] + SvgfConst<T>::eps());
+                T w_l = cvt<T>(::expf(num / den));
+                T hw = h * (wzn * w_l);
+                if (tfinite(hw)) {
+                    V4<T> cq = in[l][q];
+                    if (tfinite(cq.w)) {
+                        nvar[l] = nvar[l] + hw * hw * cq.w;
+                        wv[l] = wv[l] + hw;
+                    }
+                    if (tfinite(cq.x) && tfinite(cq.y) && tfinite(cq.z)) {
+                        ncol[l] = ncol[l] + hw * xyz(cq);
+                        wc[l] = wc[l] + hw;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+        T nv = tdiv(nvar[l], wv[l] * wv[l]);
+        V3<T> nc = vdiv(ncol[l], wc[l]);
+        V4<T> centre = in[l][p];
+        value_or(nc, xyz(centre));
+        if (!tfinite(nv))
+            nv = centre.w;
+        out[l][p] = mk4(nc.x, nc.y, nc.z, nv);
+    }
+}
+
+// ---- add_denoised_color + temporal_anti_aliasing + write_to_surface2d + copy_last_frame_pixel_id ---------------------
+template <typename T>
+__global__ void __launch_bounds__(256) k_finalize(SceneDev<T> sc, FrameDev<T> fb, const V4<T> *gi_colored, const V4<T> *gi_white,
+                                                  V4<T> *taa_next, int add_colored, int add_white, int demodulate, T taa_w) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= fb.win.npix())
+        return;
+    const T zero = (T)0, one = (T)1;
+    V3<T> color = xyz(fb.color_inprogress[p]);
+    V3<T> albedo = demodulate ? mk3(one, one, one) : xyz(fb.albedo[p]);
+    if (add_colored)
+        color = color + elemul(xyz(gi_colored[p]), albedo);
+    if (add_white)
+        color = color + xyz(gi_white[p]);
+    // TAA (cuda.hpp:2418-2439)
+    V3<T> hist = sample_linear3(fb.taa_map[p], fb.taa_history, fb.win.W, color);
+    value_or(hist, color);
+    V3<T> out = hist * (one - taa_w) + color * taa_w;
+    V4<T> o4 = mk4(out.x, out.y, out.z, zero);
+    fb.color_inprogress[p] = o4;
+    taa_next[p] = o4; // history for the next frame (imgui_window.cu:260-262), double-buffered
+    const float ig = 1 / 2.2f;
+    fb.output[p] = make_float4(::powf((float)out.x, ig), ::powf((float)out.y, ig), ::powf((float)out.z, ig), 1.f);
+    // copy_last_frame_pixel_id (cuda.hpp:2230-2251)
+    uint2 id;
+    if ((fb.g_color[p] >> 24) == 0) {
+        id = make_uint2(0xffffffffu, fb.last_frame_id[p].y);
+    } else {
+        id = make_uint2(sc.objects[fb.g_objid[p]].objectid, fb.g_offset[p]);
+    }
+    fb.last_frame_id[p] = id;
+    fb.prev_frame_count[p] = fb.valid_frame_count[p]; // snapshot for the next frame's temporal map
+}
+
+// copy_last_frame_transform (cuda.hpp:2253-2263)
+template <typename T> __global__ void k_copy_last_transform(SceneDev<T> sc, M4<T> *last_L2W, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    last_L2W[sc.objects[i].objectid] = sc.objects[i].L2W;
+}
+
+// float32 read-back conversions
+template <typename T> __global__ void k_read_v4(const V4<T> *src, float *dst, uint32_t n, int channels) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n)
+        return;
+    V4<T> v = src[p];
+    float f[4] = {(float)v.x, (float)v.y, (float)v.z, (float)v.w};
+    for (int c = 0; c < channels; c++)
+        dst[(size_t)p * channels + c] = f[c];
+}
+__global__ void k_read_u32(const uint32_t *src, float *dst, uint32_t n, int rgba8) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n)
+        return;
+    uint32_t v = src[p];
+    if (rgba8) {
+        for (int c = 0; c < 4; c++)
+            dst[(size_t)p * 4 + c] = (float)((v >> (8 * c)) & 255u);
+    } else {
+        dst[p] = (float)v;
+    }
+}
+
+// ---- launchers -------------------------------------------------------------------------------------------------------
+static inline dim3 grid_for(uint32_t n) { return dim3((n + 255) / 256); }
+
+template <typename T> void launch_svgf(hipStream_t st, FrameDev<T> &fb, float color_w, float moments_w) {
+    const dim3 g = grid_for(fb.win.npix()), b(256);
+    auto to_T = [](float f) { return (T)f; };
+    hipLaunchKernelGGL(k_depth_gradient<T>, g, b, 0, st, fb);
+    hipLaunchKernelGGL(k_temporal_color<T>, g, b, 0, st, fb, to_T(color_w));
+    hipLaunchKernelGGL(k_moments<T>, g, b, 0, st, fb, to_T(moments_w));
+    SvgfLobe<T> &a = fb.lobe[0], &w = fb.lobe[1];
+    // integrated colour is in cv_c.  Rotation (cuda.hpp:1678-1710 with cv_c in the role of color_inout):
+    // L1 c->b (b = next frame's history), L2 b->a, L3 a->c, L4 c->a, L5 a->c; result in cv_c.
+    hipLaunchKernelGGL((k_wavelet<T, 1>), g, b, 0, st, fb, a.cv_c, a.cv_b, w.cv_c, w.cv_b);
+    hipLaunchKernelGGL((k_wavelet<T, 2>), g, b, 0, st, fb, a.cv_b, a.cv_a, w.cv_b, w.cv_a);
+    hipLaunchKernelGGL((k_wavelet<T, 4>), g, b, 0, st, fb, a.cv_a, a.cv_c, w.cv_a, w.cv_c);
+    hipLaunchKernelGGL((k_wavelet<T, 8>), g, b, 0, st, fb, a.cv_c, a.cv_a, w.cv_c, w.cv_a);
+    hipLaunchKernelGGL((k_wavelet<T, 16>), g, b, 0, st, fb, a.cv_a, a.cv_c, w.cv_a, w.cv_c);
+    // moments history for the next frame: swap instead of the reference's (short) memcpy (DEVIATION Q8)
+    for (int l = 0; l < 2; l++) {
+        std::swap(fb.lobe[l].miu1_hist, fb.lobe[l].miu1_cur);
+        std::swap(fb.lobe[l].miu2_hist, fb.lobe[l].miu2_cur);
+    }
+}
+template <typename T>
+void launch_finalize(hipStream_t st, const SceneDev<T> &sc, FrameDev<T> &fb, const V4<T> *gi_colored, const V4<T> *gi_white, V4<T> *taa_next,
+                     bool add_colored, bool add_white, bool demodulate, float taa_w, uint32_t n_objects) {
+    hipLaunchKernelGGL(k_finalize<T>, grid_for(fb.win.npix()), dim3(256), 0, st, sc, fb, gi_colored, gi_white, taa_next, add_colored ? 1 : 0,
+                       add_white ? 1 : 0, demodulate ? 1 : 0, (T)taa_w);
+    if (n_objects)
+        hipLaunchKernelGGL(k_copy_last_transform<T>, dim3((n_objects + 63) / 64), dim3(64), 0, st, sc, fb.last_frame_L2W, n_objects);
+}
+template <typename T> void launch_read_v4(hipStream_t st, const V4<T> *src, float *dst, uint32_t n, int channels) {
+    hipLaunchKernelGGL(k_read_v4<T>, grid_for(n), dim3(256), 0, st, src, dst, n, channels);
+}
+void launch_read_u32(hipStream_t st, const uint32_t *src, float *dst, uint32_t n, bool rgba8) {
+    hipLaunchKernelGGL(k_read_u32, grid_for(n), dim3(256), 0, st, src, dst, n, rgba8 ? 1 : 0);
+}
+
+#define INST(T)                                                                                                        \
+    template void launch_svgf<T>(hipStream_t, FrameDev<T> &, float, float);                                            \
+    template void launch_finalize<T>(hipStream_t, const SceneDev<T> &, FrameDev<T> &, const V4<T> *, const V4<T> *,    \
+                                     V4<T> *, bool, bool, bool, float, uint32_t);                                      \
+    template void launch_read_v4<T>(hipStream_t, const V4<T> *, float *, uint32_t, int);
+INST(float)
+INST(h16)
+#undef INST
+
+} // namespace lprt

@@ -1,0 +1,329 @@
+// Device ray casting: two-level traversal + the reference's mixed-precision triangle test.
+//
+// Replaces Ray/Intersection, ray_aabb_intersection_{scene,object}, ray_triangle_intersection,
+// search_intersection_in_object, scene_bvh.traversal and cast_ray (rt/rtrt/cuda.hpp:38-149, 193-354,
+// 415-631).  What is kept bit-for-bit is the ARITHMETIC that decides hits (slab tests with the same
+// slack constants, the precomputed-transform triangle test with its fp32 t and fp32 edge-zone re-test,
+// ray transform without renormalisation).  What is NOT kept is the reference's stackless
+// parent-pointer walk over 1-primitive leaves: traversal here runs over an implicit perfect tree with
+// child boxes stored in the parent, near-child-first, with a one-bit-per-level "pending sibling" mask
+// instead of a stack (no LDS, no scratch).  Closest-hit results are order independent except at exact
+// t ties.
+#pragma once
+#include "types.hpp"
+
+namespace lprt {
+
+template <typename T> LPRT_DEV float ray_moveforward_t() { return Num<T>::is_half ? 1e-1f : 1e-4f; } // cuda.hpp:934-942
+
+// Ray::transformed (cuda.hpp:42-47): position divided by w, direction NOT renormalised.
+template <typename T> LPRT_DEV RayT<T> transform_ray(const RayT<T> &r, const M4<T> &m) {
+    RayT<T> o;
+    o.o = xform_pos(m, r.o);
+    o.d = xform_dir(m, r.d);
+    return o;
+}
+
+// per-ray constants for the slab tests: 1/d in f32 (IEEE); see DESIGN.md "slab test"
+template <typename T> struct RaySlab {
+    V3<T> o;
+    float ix, iy, iz;
+};
+template <typename T> LPRT_DEV RaySlab<T> make_slab(const RayT<T> &r) {
+    return {r.o, 1.0f / (float)r.d.x, 1.0f / (float)r.d.y, 1.0f / (float)r.d.z};
+}
+template <typename T> LPRT_DEV T slab_t(T bound, T origin, float inv) {
+    // (bound - origin) / d with the quotient formed as a product with the f32 reciprocal and rounded to T
+    return cvt<T>((float)(bound - origin) * inv);
+}
+
+// ray_aabb_intersection_scene / _object (cuda.hpp:70-149). Axes whose entry/exit is not finite are
+// ignored (parallel rays), as in the reference.
+template <typename T, bool SCENE> LPRT_DEV bool slab_test(const T *lo, const T *hi, const RaySlab<T> &rs, T &tmn, T &tmx) {
+    T a0 = slab_t(lo[0], rs.o.x, rs.ix), b0 = slab_t(hi[0], rs.o.x, rs.ix);
+    T a1 = slab_t(lo[1], rs.o.y, rs.iy), b1 = slab_t(hi[1], rs.o.y, rs.iy);
+    T a2 = slab_t(lo[2], rs.o.z, rs.iz), b2 = slab_t(hi[2], rs.o.z, rs.iz);
+    if (b0 < a0) { T s = a0; a0 = b0; b0 = s; }
+    if (b1 < a1) { T s = a1; a1 = b1; b1 = s; }
+    if (b2 < a2) { T s = a2; a2 = b2; b2 = s; }
+    bool upd = false;
+    T t1max = (T)0, t2min = (T)0;
+    if (tfinite(a0) && tfinite(b0)) { t1max = a0; t2min = b0; upd = true; }
+    if (tfinite(a1) && tfinite(b1)) {
+        if (!upd || t1max < a1) t1max = a1;
+        if (!upd || b1 < t2min) t2min = b1;
+        upd = true;
+    }
+    if (tfinite(a2) && tfinite(b2)) {
+        if (!upd || t1max < a2) t1max = a2;
+        if (!upd || b2 < t2min) t2min = b2;
+        upd = true;
+    }
+    if (!upd)
+        return false;
+    bool out;
+    if (SCENE) {
+        T s = t2min + cvt<T>(0.02f);
+        out = t1max <= s && 0.0f <= (float)s;
+    } else {
+        out = t1max <= t2min * cvt<T>(1.001953f) && 0.0f <= (float)t2min;
+    }
+    tmn = t1max;
+    tmx = t2min;
+    return out;
+}
+
+template <bool COUNT> struct Cnt {
+    unsigned rays = 0, tlas_nodes = 0, aabbw = 0, objects = 0, blas_nodes = 0, tris = 0, fallbacks = 0;
+};
+
+// ---- T3: ray_triangle_intersection (cuda.hpp:193-354) ---------------------------------------------
+template <typename T> LPRT_DEV void load_fallback(const SceneDev<T> &sc, uint32_t rec, const TriRec<T> &r, TriRecF32 &f);
+template <> LPRT_DEV void load_fallback<float>(const SceneDev<float> &, uint32_t, const TriRec<float> &r, TriRecF32 &f) {
+    // DataT = float: M_shift_f32 == M_shift and position_f32 == position
+    f.m0[0] = r.m0[0]; f.m0[1] = r.m0[1]; f.m0[2] = r.m0[2]; f.v2x = r.v2x;
+    f.m1[0] = r.m1[0]; f.m1[1] = r.m1[1]; f.m1[2] = r.m1[2]; f.v2y = r.v2y;
+    f.m2[0] = r.m2[0]; f.m2[1] = r.m2[1]; f.m2[2] = r.m2[2]; f.v2z = r.v2z;
+}
+template <> LPRT_DEV void load_fallback<h16>(const SceneDev<h16> &sc, uint32_t rec, const TriRec<h16> &, TriRecF32 &f) {
+    f = sc.tris_f32[rec];
+}
+
+template <typename T, bool COUNT>
+LPRT_DEV bool tri_test(const SceneDev<T> &sc, uint32_t rec, const RayT<T> &ray, uint32_t inscene_objid, Isect<T> &is,
+                       T min_distance, T max_distance, Cnt<COUNT> &cnt) {
+    LPRT_CHECK_RET(sc, rec < sc.lim_tris, 201, rec, sc.lim_tris, false);
+    const TriRec<T> r = sc.tris[rec];
+    if (COUNT)
+        cnt.tris++;
+    T O0 = ray.o.x - r.v2x, O1 = ray.o.y - r.v2y, O2 = ray.o.z - r.v2z;
+    T D0 = ray.d.x, D1 = ray.d.y, D2 = ray.d.z;
+    T Ox_0 = O0 * r.m0[0], Ox_1 = O1 * r.m0[1], Ox_2 = O2 * r.m0[2];
+    T Dx_0 = D0 * r.m0[0], Dx_1 = D1 * r.m0[1], Dx_2 = D2 * r.m0[2];
+    T Oy_0 = O0 * r.m1[0], Oy_1 = O1 * r.m1[1], Oy_2 = O2 * r.m1[2];
+    T Dy_0 = D0 * r.m1[0], Dy_1 = D1 * r.m1[1], Dy_2 = D2 * r.m1[2];
+    T Ox = Ox_0 + Ox_1 + Ox_2;
+    T Dx = Dx_0 + Dx_1 + Dx_2;
+    T Oy = Oy_0 + Oy_1 + Oy_2;
+    T Dy = Dy_0 + Dy_1 + Dy_2;
+    // row 2 and t always in fp32, from the DataT-rounded operands (cuda.hpp:234-240)
+    float Oz = (float)O0 * (float)r.m2[0] + (float)O1 * (float)r.m2[1] + (float)O2 * (float)r.m2[2];
+    float Dz = (float)D0 * (float)r.m2[0] + (float)D1 * (float)r.m2[1] + (float)D2 * (float)r.m2[2];
+    float invDz = 1.0f / Dz;
+    float t = -Oz * invDz;
+    T t_Dx = cvt<T>(t * (float)Dx);
+    T t_Dy = cvt<T>(t * (float)Dy);
+    T u = Ox + t_Dx;
+    T v = Oy + t_Dy;
+
+    if (!(t > (float)min_distance && t < (float)is.t && t < (float)max_distance))
+        return false;
+
+    // running error bounds (cuda.hpp:247-261)
+    const T delta1 = cvt<T>(0.0009765625f); // 2^-10
+    const T delta2 = cvt<T>(0.00390625f);   // 2^-8
+    T sOx = tabs(Ox_0) + tabs(Ox_1) + tabs(Ox_2);
+    T sDx = tabs(Dx_0) + tabs(Dx_1) + tabs(Dx_2);
+    T sOy = tabs(Oy_0) + tabs(Oy_1) + tabs(Oy_2);
+    T sDy = tabs(Dy_0) + tabs(Dy_1) + tabs(Dy_2);
+    T error_Ox = delta1 * sOx + delta2 * sOx;
+    T error_Dx = delta1 * sDx + delta2 * sDx;
+    T error_Oy = delta1 * sOy + delta2 * sOy;
+    T error_Dy = delta1 * sDy + delta2 * sDy;
+    T tT = cvt<T>(t);
+    T error_u = (error_Ox + tT * error_Dx + delta1 * (tabs(Ox) + cvt<T>(3.f) * tabs(t_Dx))) * cvt<T>(0.2f);
+    T error_v = (error_Oy + tT * error_Dy + delta1 * (tabs(Oy) + cvt<T>(3.f) * tabs(t_Dy))) * cvt<T>(0.2f);
+
+    float w = 1.0f - (float)u - (float)v; // `1 - u - v` is evaluated in float for both DataT
+    T zero = (T)0;
+    if ((u >= tneg(error_u) && u <= zero) || (v >= tneg(error_v) && v <= zero) ||
+        (w >= (float)tneg((T)(error_v + error_u)) && w <= 0.0f)) {
+        // edge zone: recompute everything in fp32 with strict inequalities (cuda.hpp:267-328)
+        if (COUNT)
+            cnt.fallbacks++;
+        TriRecF32 f;
+        load_fallback<T>(sc, rec, r, f);
+        float Of0 = (float)ray.o.x - f.v2x, Of1 = (float)ray.o.y - f.v2y, Of2 = (float)ray.o.z - f.v2z;
+        float Df0 = (float)ray.d.x, Df1 = (float)ray.d.y, Df2 = (float)ray.d.z;
+        float Oxf = Of0 * f.m0[0] + Of1 * f.m0[1] + Of2 * f.m0[2];
+        float Dxf = Df0 * f.m0[0] + Df1 * f.m0[1] + Df2 * f.m0[2];
+        float Oyf = Of0 * f.m1[0] + Of1 * f.m1[1] + Of2 * f.m1[2];
+        float Dyf = Df0 * f.m1[0] + Df1 * f.m1[1] + Df2 * f.m1[2];
+        float Ozf = Of0 * f.m2[0] + Of1 * f.m2[1] + Of2 * f.m2[2];
+        float Dzf = Df0 * f.m2[0] + Df1 * f.m2[1] + Df2 * f.m2[2];
+        float tf = -Ozf / Dzf;
+        float uf = Oxf + tf * Dxf;
+        float vf = Oyf + tf * Dyf;
+        if (tf > (float)min_distance && tf < (float)is.t && tf < (float)max_distance) {
+            if (uf > 0 && vf > 0 && uf + vf < 1) {
+                is.hit = true;
+                is.t = cvt<T>(tf);
+                is.bary = mk3(cvt<T>(uf), cvt<T>(vf), cvt<T>(1 - uf - vf));
+                is.inobject_offset = r.inobject_offset;
+                is.inscene_objid = inscene_objid;
+                return true;
+            }
+        }
+        return false;
+    }
+    if (u > tneg(error_u)) {
+        // `DataT(1.0 + error_u + error_v)`: double sum, then double -> float -> DataT (cuda.hpp:332)
+        T lim = cvt<T>((float)(1.0 + (double)(float)error_u + (double)(float)error_v));
+        if (v > tneg(error_v) && u + v < lim) {
+            is.hit = true;
+            is.t = tT;
+            is.bary = mk3(u, v, cvt<T>(w));
+            is.inobject_offset = r.inobject_offset;
+            is.inscene_objid = inscene_objid;
+            return true;
+        }
+    }
+    return false;
+}
+
+// ---- T4: BLAS traversal (replaces search_intersection_in_object, cuda.hpp:415-504) -----------------
+template <typename T, bool ANY, bool COUNT>
+LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, uint32_t inscene_objid, uint32_t vao_index,
+                            uint32_t skip_vao, uint32_t skip_off, Isect<T> &is, T min_distance, T max_distance,
+                            Cnt<COUNT> &cnt) {
+    LPRT_CHECK(sc, vao_index < sc.n_vaos, 202, vao_index, sc.n_vaos);
+    const BlasInfo bi = sc.blas[vao_index];
+    if (COUNT)
+        cnt.objects++;
+    if (bi.n_tris == 0)
+        return;
+    const RaySlab<T> rs = make_slab(ray);
+    T tmn, tmx;
+    if (COUNT)
+        cnt.blas_nodes++;
+    const T *rb = sc.blas_roots + 6 * bi.root_base;
+    if (!(slab_test<T, false>(rb, rb + 3, rs, tmn, tmx) && tmn < is.t && tmn < max_distance && tmx > min_distance))
+        return;
+    const InnerNode<T> *inner = sc.blas_inner + bi.inner_base;
+    const uint32_t *leaves = sc.blas_leaf + bi.leaf_base;
+    const uint32_t D = bi.depth;
+    const bool skip_here = (vao_index == skip_vao);
+    uint32_t i = 1, c = 0, pending = 0;
+    for (;;) {
+        if (c < D) {
+            LPRT_CHECK(sc, bi.inner_base + i - 1 < sc.lim_inner, 203, bi.inner_base + i - 1, sc.lim_inner);
+            const InnerNode<T> nd = inner[i - 1];
+            if (COUNT)
+                cnt.blas_nodes += 2;
+            T n0, x0, n1, x1;
+            bool h0 = slab_test<T, false>(nd.lo0, nd.hi0, rs, n0, x0) && n0 < is.t && n0 < max_distance && x0 > min_distance;
+            bool h1 = slab_test<T, false>(nd.lo1, nd.hi1, rs, n1, x1) && n1 < is.t && n1 < max_distance && x1 > min_distance;
+            if (h0 | h1) {
+                uint32_t first = (h0 && (!h1 || n0 <= n1)) ? 0u : 1u;
+                if (h0 & h1)
+                    pending |= 1u << (c + 1);
+                i = 2 * i + first;
+                c++;
+                continue;
+            }
+        } else {
+            LPRT_CHECK(sc, bi.leaf_base + i - (1u << D) < sc.lim_leaves, 204, bi.leaf_base + i - (1u << D), sc.lim_leaves);
+            uint32_t lw = leaves[i - (1u << D)];
+            uint32_t first = bi.tri_base + (lw >> 1), count = (lw & 1u) + 1u;
+            for (uint32_t k = 0; k < count; k++) {
+                uint32_t rec = first + k;
+                if (skip_here && sc.tris[rec].inobject_offset == skip_off) // cuda.hpp:446
+                    continue;
+                tri_test<T, COUNT>(sc, rec, ray, inscene_objid, is, min_distance, max_distance, cnt);
+                if (ANY && is.hit)
+                    return;
+            }
+        }
+        if (!pending)
+            return;
+        uint32_t d = 31u - (uint32_t)__builtin_clz(pending);
+        pending ^= 1u << d;
+        i = (i >> (c - d)) ^ 1u;
+        c = d;
+    }
+}
+
+// ---- T5: TLAS traversal + cast_ray (cuda.hpp:517-631) ---------------------------------------------
+template <typename T, bool ANY, bool COUNT>
+LPRT_DEV Isect<T> cast_ray(const SceneDev<T> &sc, const RayT<T> &ray, uint32_t skip_vao, uint32_t skip_off, T min_distance,
+                           T max_distance, Cnt<COUNT> &cnt) {
+    Isect<T> is;
+    is.hit = false;
+    is.t = cvt<T>(1e5f); // +inf in half (cuda.hpp:54)
+    is.inscene_objid = 0;
+    is.inobject_offset = 0;
+    is.bary = zero3<T>();
+    if (COUNT)
+        cnt.rays++;
+    if (sc.n_objects == 0)
+        return is;
+    const RaySlab<T> rs = make_slab(ray);
+    T tmn, tmx;
+    if (COUNT)
+        cnt.tlas_nodes++;
+    if (!(slab_test<T, true>(sc.tlas_root, sc.tlas_root + 3, rs, tmn, tmx) && tmn < max_distance && tmx > min_distance))
+        return is;
+    const uint32_t D = sc.tlas_depth;
+    uint32_t i = 1, c = 0, pending = 0;
+    for (;;) {
+        if (c < D) {
+            const InnerNode<T> nd = sc.tlas_inner[i - 1];
+            if (COUNT)
+                cnt.tlas_nodes += 2;
+            T n0, x0, n1, x1;
+            // no `tmin < intersection.t` cull at the scene level (cuda.hpp:536-538)
+            bool h0 = slab_test<T, true>(nd.lo0, nd.hi0, rs, n0, x0) && n0 < max_distance && x0 > min_distance;
+            bool h1 = slab_test<T, true>(nd.lo1, nd.hi1, rs, n1, x1) && n1 < max_distance && x1 > min_distance;
+            if (h0 | h1) {
+                uint32_t first = (h0 && (!h1 || n0 <= n1)) ? 0u : 1u;
+                if (h0 & h1)
+                    pending |= 1u << (c + 1);
+                i = 2 * i + first;
+                c++;
+                continue;
+            }
+        } else {
+            uint32_t lw = sc.tlas_leaf[i - (1u << D)];
+            uint32_t first = lw >> 1, count = (lw & 1u) + 1u;
+            for (uint32_t k = 0; k < count; k++) {
+                LPRT_CHECK_RET(sc, first + k < sc.n_objects, 205, first + k, sc.n_objects, is);
+                const ObjSlot<T> slot = sc.tlas_slots[first + k];
+                LPRT_CHECK_RET(sc, slot.inscene_objid < sc.lim_objects, 206, slot.inscene_objid, sc.lim_objects, is);
+                if (COUNT)
+                    cnt.aabbw++;
+                if (slab_test<T, true>(slot.lo, slot.hi, rs, tmn, tmx) && tmn < max_distance && tmx > min_distance) {
+                    const ObjConst<T> *oc = sc.objects + slot.inscene_objid;
+                    RayT<T> lr = transform_ray(ray, oc->W2L);
+                    traverse_blas<T, ANY, COUNT>(sc, lr, slot.inscene_objid, oc->objectid, skip_vao, skip_off, is,
+                                                 min_distance, max_distance, cnt);
+                    if (ANY && is.hit)
+                        return is;
+                }
+            }
+        }
+        if (!pending)
+            return is;
+        uint32_t d = 31u - (uint32_t)__builtin_clz(pending);
+        pending ^= 1u << d;
+        i = (i >> (c - d)) ^ 1u;
+        c = d;
+    }
+}
+
+// wave-aggregated counter flush: one atomic per counter per wave
+template <bool COUNT> LPRT_DEV void flush_counters(const Cnt<COUNT> &c, Counters *out) {
+    if (!COUNT)
+        return;
+    unsigned vals[7] = {c.rays, c.tlas_nodes, c.aabbw, c.objects, c.blas_nodes, c.tris, c.fallbacks};
+    unsigned long long *dst = reinterpret_cast<unsigned long long *>(out);
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        unsigned v = vals[k];
+        for (int off = 32; off > 0; off >>= 1)
+            v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0 && v)
+            atomicAdd(dst + k, (unsigned long long)v);
+    }
+}
+
+} // namespace lprt

@@ -1,0 +1,130 @@
+// Ray-casting kernels: host ray batches (lprt_trace_rays), primary rays -> G-buffer (G1, G2),
+// GI rays (TG) and shadow rays (TD).
+#include "kernels.hpp"
+#include "trace.hpp"
+
+namespace lprt {
+
+// ---- lprt_trace_rays: cast_ray<find_any,false> over a batch (cuda.hpp:622-631) -------------------------
+template <typename T, bool ANY, bool COUNT>
+__global__ void __launch_bounds__(256) k_trace_rays(SceneDev<T> sc, const lprt_ray *rays, uint32_t n, lprt_hit *hits, Counters *counters) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    Cnt<COUNT> cnt;
+    if (i < n) {
+        const lprt_ray in = rays[i];
+        RayT<T> ray;
+        ray.o = mk3(cvt<T>(in.source[0]), cvt<T>(in.source[1]), cvt<T>(in.source[2]));
+        ray.d = mk3(cvt<T>(in.direction[0]), cvt<T>(in.direction[1]), cvt<T>(in.direction[2]));
+        Isect<T> is = cast_ray<T, ANY, COUNT>(sc, ray, in.skip_vao, in.skip_inobject_offset, cvt<T>(in.min_distance),
+                                              cvt<T>(in.max_distance), cnt);
+        lprt_hit h;
+        h.hit = is.hit ? 1u : 0u;
+        h.inscene_objid = is.inscene_objid;
+        h.inobject_offset = is.inobject_offset;
+        h.t = (float)is.t;
+        h.barycentric[0] = (float)is.bary.x;
+        h.barycentric[1] = (float)is.bary.y;
+        h.barycentric[2] = (float)is.bary.z;
+        hits[i] = h;
+    }
+    flush_counters<COUNT>(cnt, counters);
+}
+
+template <typename T>
+void launch_trace_rays(hipStream_t st, const SceneDev<T> &sc, const lprt_ray *rays, uint32_t n, bool any, lprt_hit *hits, Counters *counters) {
+    if (n == 0)
+        return;
+    dim3 grid((n + 255) / 256), block(256);
+    if (counters) {
+        if (any)
+            hipLaunchKernelGGL((k_trace_rays<T, true, true>), grid, block, 0, st, sc, rays, n, hits, counters);
+        else
+            hipLaunchKernelGGL((k_trace_rays<T, false, true>), grid, block, 0, st, sc, rays, n, hits, counters);
+    } else {
+        if (any)
+            hipLaunchKernelGGL((k_trace_rays<T, true, false>), grid, block, 0, st, sc, rays, n, hits, counters);
+        else
+            hipLaunchKernelGGL((k_trace_rays<T, false, false>), grid, block, 0, st, sc, rays, n, hits, counters);
+    }
+}
+template void launch_trace_rays<float>(hipStream_t, const SceneDev<float> &, const lprt_ray *, uint32_t, bool, lprt_hit *, Counters *);
+template void launch_trace_rays<h16>(hipStream_t, const SceneDev<h16> &, const lprt_ray *, uint32_t, bool, lprt_hit *, Counters *);
+
+// ---- scene constant conversion (CUDAObjectConstantData / CUDAMaterial / RDLight in DataT) -------------
+template <typename T> __global__ void k_convert_objects(const lprt_object *in, ObjConst<T> *out, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    ObjConst<T> o;
+    for (int k = 0; k < 16; k++) {
+        o.L2W.m[k] = cvt<T>(in[i].transform_L2W[k]);
+        o.W2L.m[k] = cvt<T>(in[i].transform_W2L[k]);
+    }
+    o.materialid = in[i].materialid;
+    o.objectid = in[i].objectid;
+    o.pad[0] = o.pad[1] = 0;
+    out[i] = o;
+}
+template <typename T> __global__ void k_convert_materials(const lprt_material *in, MaterialT<T> *out, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    MaterialT<T> m;
+    for (int k = 0; k < 3; k++) {
+        m.color[k] = cvt<T>(in[i].color[k]);
+        m.emission[k] = cvt<T>(in[i].emission[k]);
+    }
+    m.metallic = cvt<T>(in[i].metallic);
+    m.roughness = cvt<T>(in[i].roughness);
+    m.double_sided = in[i].double_sided;
+    m.uv_color = in[i].uv_color;
+    m.tex_color = in[i].tex_color;
+    m.pad = 0;
+    out[i] = m;
+}
+template <typename T> __global__ void k_convert_lights(const lprt_light *in, LightT<T> *out, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    LightT<T> l;
+    for (int k = 0; k < 3; k++) {
+        l.direction[k] = cvt<T>(in[i].direction[k]);
+        l.intensity[k] = cvt<T>(in[i].intensity[k]);
+        l.position[k] = cvt<T>(in[i].position[k]);
+    }
+    l.type = in[i].type;
+    out[i] = l;
+}
+template <typename T> __global__ void k_convert_mat4(const float *in, M4<T> *out, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * 16)
+        return;
+    out[i / 16].m[i % 16] = cvt<T>(in[i]);
+}
+
+template <typename T> void launch_convert_objects(hipStream_t st, const lprt_object *in, ObjConst<T> *out, uint32_t n) {
+    if (n)
+        hipLaunchKernelGGL(k_convert_objects<T>, dim3((n + 63) / 64), dim3(64), 0, st, in, out, n);
+}
+template <typename T> void launch_convert_materials(hipStream_t st, const lprt_material *in, MaterialT<T> *out, uint32_t n) {
+    if (n)
+        hipLaunchKernelGGL(k_convert_materials<T>, dim3((n + 63) / 64), dim3(64), 0, st, in, out, n);
+}
+template <typename T> void launch_convert_lights(hipStream_t st, const lprt_light *in, LightT<T> *out, uint32_t n) {
+    if (n)
+        hipLaunchKernelGGL(k_convert_lights<T>, dim3((n + 63) / 64), dim3(64), 0, st, in, out, n);
+}
+template <typename T> void launch_convert_mat4(hipStream_t st, const float *in, M4<T> *out, uint32_t n) {
+    if (n)
+        hipLaunchKernelGGL(k_convert_mat4<T>, dim3((n * 16 + 63) / 64), dim3(64), 0, st, in, out, n);
+}
+#define INST(T)                                                                                                        \
+    template void launch_convert_objects<T>(hipStream_t, const lprt_object *, ObjConst<T> *, uint32_t);                \
+    template void launch_convert_materials<T>(hipStream_t, const lprt_material *, MaterialT<T> *, uint32_t);           \
+    template void launch_convert_lights<T>(hipStream_t, const lprt_light *, LightT<T> *, uint32_t);                    \
+    template void launch_convert_mat4<T>(hipStream_t, const float *, M4<T> *, uint32_t);
+INST(float)
+INST(h16)
+#undef INST
+
+} // namespace lprt

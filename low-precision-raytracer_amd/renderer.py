@@ -1,0 +1,215 @@
+"""Host-side mirror of the reference's renderer interface over the C-ABI (include/lprt.h).
+
+`Renderer` plays the role of `Renderer<DataT>` (rt/gui/imgui_window.cu:78-367): construction allocates the
+per-pixel buffers, `set_rdresource` takes the loader's output, `render(rd_scene)` runs one frame.  There is
+no CPU fallback: if csrc/liblprt_hip.so is missing or no GPU is present this module raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class LprtError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(_HERE, "csrc", "liblprt_hip.so")
+
+
+# every symbol include/lprt.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = [
+    ("lprt_create", C.c_int, [C.POINTER(_P), C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]),
+    ("lprt_destroy", None, [_P]),
+    ("lprt_last_error", C.c_char_p, [_P]),
+    ("lprt_set_stream", C.c_int, [_P, _P]),
+    ("lprt_synchronize", C.c_int, [_P]),
+    ("lprt_upload_geometry", C.c_int, [_P, _P, C.c_uint32, _P, C.c_uint32, _P, C.c_uint32]),
+    ("lprt_upload_materials", C.c_int, [_P, _P, C.c_uint32]),
+    ("lprt_upload_texture", C.c_int, [_P, _P, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
+    ("lprt_build_blas", C.c_int, [_P]),
+    ("lprt_set_scene", C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_uint32, _P, _P, _P]),
+    ("lprt_render_frame", C.c_int, [_P, _P]),
+    ("lprt_reset_history", C.c_int, [_P]),
+    ("lprt_read_buffer", C.c_int, [_P, C.c_int, _P, C.c_size_t]),
+    ("lprt_output_device_ptr", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
+    ("lprt_trace_rays", C.c_int, [_P, _P, C.c_uint32, C.c_int, _P]),
+    ("lprt_enable_counters", C.c_int, [_P, C.c_int]),
+    ("lprt_get_counters", C.c_int, [_P, _P]),
+    ("lprt_reset_counters", C.c_int, [_P]),
+    ("lprt_enable_stage_timing", C.c_int, [_P, C.c_int]),
+    ("lprt_get_stage_times", C.c_int, [_P, _P, _P]),
+    ("lprt_reset_stage_times", C.c_int, [_P]),
+    ("lprt_get_blas_info", C.c_int, [_P, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    ("lprt_read_blas_order", C.c_int, [_P, C.c_uint32, _P, C.c_uint32]),
+    ("lprt_read_blas_boxes", C.c_int, [_P, C.c_uint32, _P, C.c_uint32]),
+    ("lprt_version", C.c_char_p, []),
+]
+
+
+def load_library():
+    """dlopen the HIP library and bind every entry point; raises LprtError when it is not built."""
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise LprtError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(there is no CPU fallback)")
+        lib = C.CDLL(path)
+        for name, restype, argtypes in SYMBOLS:
+            fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _LIB = lib
+    return _LIB
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Renderer:
+    """One renderer instance for rows [row_begin, row_end) of a width x height frame on one GPU."""
+
+    def __init__(self, width, height, precision=abi.F32, device=0, row_begin=0, row_end=None):
+        self.L = load_library()
+        self.W, self.H = int(width), int(height)
+        self.row_begin = int(row_begin)
+        self.row_end = self.H if row_end is None else int(row_end)
+        self.rows = self.row_end - self.row_begin
+        self.precision = precision
+        self.h = C.c_void_p()
+        rc = self.L.lprt_create(C.byref(self.h), device, self.W, self.H, self.row_begin, self.row_end, precision)
+        if rc != abi.OK:
+            msg = self.L.lprt_last_error(None).decode()
+            self.h = None
+            raise LprtError(f"lprt_create failed ({rc}): {msg}")
+        self.scene = None
+
+    # ---- plumbing -------------------------------------------------------------------------------
+    def _check(self, rc, what):
+        if rc != abi.OK:
+            raise LprtError(f"{what} failed ({rc}): {self.L.lprt_last_error(self.h).decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lprt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, hip_stream):
+        """Enqueue all work on this hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
+        self._check(self.L.lprt_set_stream(self.h, C.c_void_p(int(hip_stream))), "lprt_set_stream")
+
+    def synchronize(self):
+        self._check(self.L.lprt_synchronize(self.h), "lprt_synchronize")
+
+    # ---- loader side: Renderer::set_rdresource (imgui_window.cu:332-337) ----------------------------
+    def set_rdresource(self, sc, build=True):
+        self.scene = sc
+        verts = np.ascontiguousarray(sc.vertices)
+        idx = np.ascontiguousarray(sc.indices, dtype=np.uint32)
+        vaos = sc.c_vaos()
+        self._check(self.L.lprt_upload_geometry(self.h, _ptr(verts), len(verts), _ptr(idx), len(idx), C.byref(vaos),
+                                                len(vaos)), "lprt_upload_geometry")
+        mats = sc.c_materials()
+        self._check(self.L.lprt_upload_materials(self.h, C.byref(mats), len(mats)), "lprt_upload_materials")
+        if build:
+            self.build_blas()
+
+    def build_blas(self):
+        self._check(self.L.lprt_build_blas(self.h), "lprt_build_blas")
+
+    # ---- scene-manager side: the RDScene of this frame ------------------------------------------------
+    def set_scene(self, sc=None):
+        sc = sc or self.scene
+        objs, aabbs, lights = sc.c_objects(), sc.c_aabbs(), sc.c_lights()
+        cam = sc.c_camera(self.W, self.H)
+        w2c = np.ascontiguousarray(sc.transform_W2C(self.W, self.H), dtype=np.float32)
+        self._check(self.L.lprt_set_scene(self.h, C.byref(objs), C.byref(aabbs), len(sc.objects), C.byref(lights),
+                                          len(sc.lights), C.byref(cam), _ptr(w2c), None), "lprt_set_scene")
+
+    def load_scene(self, sc):
+        self.set_rdresource(sc)
+        self.set_scene(sc)
+
+    # ---- Renderer::render (imgui_window.cu:339-347) ----------------------------------------------------
+    def render(self, settings=None):
+        settings = settings or abi.default_settings()
+        self._settings_keepalive = settings
+        self._check(self.L.lprt_render_frame(self.h, C.byref(settings)), "lprt_render_frame")
+
+    render_frame = render
+
+    def reset_history(self):
+        self._check(self.L.lprt_reset_history(self.h), "lprt_reset_history")
+
+    def read(self, name):
+        bid = abi.BUF[name] if isinstance(name, str) else name
+        out = np.empty((self.rows, self.W, abi.BUF_CHANNELS[bid]), dtype=np.float32)
+        self._check(self.L.lprt_read_buffer(self.h, bid, _ptr(out), out.size), "lprt_read_buffer")
+        return out
+
+    def output_device_ptr(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self.L.lprt_output_device_ptr(self.h, C.byref(p), C.byref(n)), "lprt_output_device_ptr")
+        return p.value, n.value
+
+    # ---- ray batches / instrumentation ---------------------------------------------------------------------
+    def trace(self, rays, find_any=False):
+        rays = np.ascontiguousarray(rays, dtype=abi.RAY_DTYPE)
+        hits = np.zeros(len(rays), dtype=abi.HIT_DTYPE)
+        self._check(self.L.lprt_trace_rays(self.h, _ptr(rays), len(rays), int(find_any), _ptr(hits)), "lprt_trace_rays")
+        return hits
+
+    def enable_counters(self, on=True):
+        self._check(self.L.lprt_enable_counters(self.h, int(on)), "lprt_enable_counters")
+
+    def counters(self):
+        c = abi.Counters()
+        self._check(self.L.lprt_get_counters(self.h, C.byref(c)), "lprt_get_counters")
+        return c.as_dict()
+
+    def reset_counters(self):
+        self._check(self.L.lprt_reset_counters(self.h), "lprt_reset_counters")
+
+    def enable_stage_timing(self, on=True):
+        self._check(self.L.lprt_enable_stage_timing(self.h, int(on)), "lprt_enable_stage_timing")
+
+    def stage_times(self):
+        ms = (C.c_float * len(abi.STAGES))()
+        n = (C.c_uint32 * len(abi.STAGES))()
+        self._check(self.L.lprt_get_stage_times(self.h, ms, n), "lprt_get_stage_times")
+        return {s: (float(ms[i]), int(n[i])) for i, s in enumerate(abi.STAGES)}
+
+    def reset_stage_times(self):
+        self._check(self.L.lprt_reset_stage_times(self.h), "lprt_reset_stage_times")
+
+    def blas_info(self, vao):
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._check(self.L.lprt_get_blas_info(self.h, vao, C.byref(a), C.byref(b), C.byref(c)), "lprt_get_blas_info")
+        return dict(n_tris=a.value, n_nodes=b.value, depth=c.value)
+
+    def blas_order(self, vao):
+        n = self.blas_info(vao)["n_tris"]
+        out = np.zeros(n, dtype=np.uint32)
+        self._check(self.L.lprt_read_blas_order(self.h, vao, _ptr(out), n), "lprt_read_blas_order")
+        return out
+
+    def blas_boxes(self, vao):
+        n = self.blas_info(vao)["n_nodes"]
+        out = np.zeros((n, 6), dtype=np.float32)
+        self._check(self.L.lprt_read_blas_boxes(self.h, vao, _ptr(out), n), "lprt_read_blas_boxes")
+        return out
