@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mray/s and frames/s of the path-tracing hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step is one frame of BASELINE.json configs[1]: generated Cornell box, 1920x1080, 4 spp, fp32, GI on, SVGF on,
+TLAS rebuilt per frame as the reference does.  The same run also measures configs[2] (packed fp16) and reports
+it under "fp16".  Inputs (geometry, BVH, materials) are resident in HBM before the timed region starts.
+With N GPUs the frame is cut into N row strips (+ SVGF halo) and completed by one RCCL all-gather per frame
+(lprt_amd.dist); total work is fixed, so scaling is "strong".
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import lprt_amd  # noqa: E402
+from lprt_amd import abi, scenes, dist as lp_dist  # noqa: E402
+
+HBM_PEAK = 8.0e12  # B/s, /opt/skills/guides/MI355X_MICROARCH.md (spec; ~6.3e12 achievable)
+
+# ---- algorithmic bytes, reference layout sizes fp32 | fp16 ------------------------------
+S_NODE, S_AABB, S_OBJ, S_TRI, S_FALLBACK = (40, 28), (24, 12), (136, 72), (52, 28), (48, 48)
+RAY_IO = {  # bytes per ray: command in + record out
+    "primary": (76, 44),                 # 7 G-buffer surfaces written
+    "trace_di1": (56 + 8 + 12, 36 + 8 + 6),  # TraceLightCommand + skip in, di_intensity out
+    "trace_di2": (56 + 8 + 12, 36 + 8 + 6),
+    "trace_gi": (28 + 8 + 80, 16 + 8 + 48),  # TraceGICommand + skip in, PixelShaderInput out
+}
+PIXEL_BYTES = {  # compulsory bytes per pixel per launch of the streaming kernels (both SVGF lobes per launch)
+    "shade1": (460, 236), "shade2": (324, 206), "compose": (72, 36), "temporal_map": (100, 80), "rng": (20, 20),
+    "svgf_gradient": (40, 20), "svgf_temporal": (152, 81), "svgf_moments": (168, 90), "svgf_wavelet": (120, 64),
+    "finalize": (128, 70), "backup": (0, 0),
+}
+
+
+def trace_bytes(counters, stage, prec):
+    i = 0 if prec == abi.F32 else 1
+    c = counters
+    return (c["tlas_node_visits"] * S_NODE[i] + c["blas_node_visits"] * S_NODE[i] + c["aabbw_tests"] * S_AABB[i] +
+            c["object_visits"] * S_OBJ[i] + c["tri_tests"] * S_TRI[i] + c["fallback_tests"] * S_FALLBACK[i] +
+            c["rays"] * RAY_IO[stage][i])
+
+
+def dist_info():
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    return rank, world, local
+
+
+def barrier_sync(world):
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+
+
+def measure(prec, sc, W, H, spp, steps, warmup, rank, world, device, stage_timing=True):
+    """Times `steps` frames; returns a dict (identical on every rank for the reduced fields)."""
+    win_b, win_e = lp_dist.window_rows(H, world, rank)
+    r = lprt_amd.Renderer(W, H, prec, device=device, row_begin=win_b, row_end=win_e)
+    r.set_stream(torch.cuda.current_stream().cuda_stream)
+    frame = lp_dist.ShardedFrame(W, H, rank, world, torch.device("cuda", device))
+    ptr, first_row, n_rows = frame.target()
+    r.set_output_target(ptr, first_row, n_rows)
+    r.load_scene(sc)
+    fs = abi.default_settings(spp=spp, gi_on=True, svgf=True)
+
+    def step():
+        r.set_scene(sc)   # per-frame RDScene hand-over + TLAS rebuild (rt/rtrt/cuda.hpp:662-710)
+        r.render(fs)
+        frame.all_gather()
+
+    # rays of one whole frame and per-kernel work counters: one instrumented, untimed frame of the full image
+    frame_rays, stage_counters = None, {}
+    if rank == 0:
+        full = r if world == 1 else lprt_amd.Renderer(W, H, prec, device=device)
+        if world > 1:
+            full.load_scene(sc)
+        full.enable_counters(True)
+        full.reset_counters()
+        full.set_scene(sc)
+        full.render(fs)
+        full.synchronize()
+        frame_rays = full.counters()["rays"]
+        for st in ("primary", "trace_di1", "trace_gi", "trace_di2"):
+            stage_counters[st] = full.stage_counters(st)
+        full.enable_counters(False)
+        if world > 1:
+            full.close()
+        else:
+            r.reset_history()
+    if world > 1:
+        t = torch.tensor([frame_rays or 0], dtype=torch.int64, device=f"cuda:{device}")
+        torch.distributed.broadcast(t, 0)
+        frame_rays = int(t.item())
+
+    for _ in range(warmup):
+        step()
+    r.enable_stage_timing(stage_timing)
+    r.reset_stage_times()
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier_sync(world)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{device}")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    stage = r.stage_times() if stage_timing else {}
+    r.enable_stage_timing(False)
+    out_ok = bool(torch.isfinite(frame.image).all().item())
+    res = dict(dt=dt, ms_per_step=1e3 * dt / steps, frames_per_s=steps / dt, frame_rays=frame_rays,
+               mrays_per_s=frame_rays * steps / dt / 1e6, stage=stage, stage_counters=stage_counters,
+               finite=out_ok, window_rows=[win_b, win_e])
+    r.close()
+    return res
+
+
+def roofline_of(res, prec, npix_window, spp):
+    """Dominant kernel family of the timed region (largest summed HIP-event time) against the HBM roof."""
+    i = 0 if prec == abi.F32 else 1
+    best = None
+    for name, (ms, launches) in res["stage"].items():
+        if launches == 0 or name in ("build_blas", "build_tlas"):
+            continue
+        if best is None or ms > best[1]:
+            best = (name, ms, launches)
+    if best is None:
+        return None
+    name, ms, launches = best
+    avg_s = ms / launches / 1e3
+    if name in RAY_IO:
+        per_frame = trace_bytes(res["stage_counters"][name], name, prec)
+        launches_per_frame = 1 if name == "primary" else spp
+        bytes_per_launch = per_frame / launches_per_frame
+        basis = "visit counters x reference record sizes (SURVEY.md 8(d))"
+    else:
+        bytes_per_launch = PIXEL_BYTES[name][i] * npix_window
+        basis = "compulsory bytes/pixel x pixels (SURVEY.md 8(a))"
+    achieved = bytes_per_launch / avg_s
+    return {"bound": "hbm", "kernel": abi.STAGE_KERNELS.get(name, name), "stage": name, "achieved": achieved / 1e9,
+            "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+            "avg_launch_us": avg_s * 1e6, "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
+            "basis": basis}
+
+
+def cpu_baseline(sc, spp):
+    """The CPU oracle (a port of the reference pipeline; the reference has no CPU path) on a bounded sample:
+    1/16 of the 1080p frame."""
+    from oracle.binding import Oracle
+    W, H = 480, 270
+    cores = min(len(os.sched_getaffinity(0)), 32)  # the GPU box grants a CPU share; more threads than that only thrash
+    o = Oracle(W, H, abi.F32, threads=cores)
+    o.load_scene(sc)
+    fs = abi.default_settings(spp=spp, gi_on=True, svgf=True)
+    o.reset_counters()
+    t0 = time.perf_counter()
+    o.set_scene(sc)
+    o.render_frame(fs)
+    dt = time.perf_counter() - t0
+    rays = o.counters()["rays"]
+    o.close()
+    return {"value": rays / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
+            "sample": f"cornell_box {W}x{H} (1/16 of the 1080p frame), {spp} spp, fp32, gi+svgf on, 1 frame, {dt:.1f} s",
+            "frames_per_s": 1.0 / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=4)
+    ap.add_argument("--scene", default="cornell")
+    ap.add_argument("--no-fp16", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stage-timing", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local = dist_info()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the renderer has no CPU fallback")
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    sc = scenes.SCENES[args.scene]()
+    W, H, spp = args.width, args.height, args.spp
+    res32 = measure(abi.F32, sc, W, H, spp, args.steps, args.warmup, rank, world, local, not args.no_stage_timing)
+    res16 = None if args.no_fp16 else measure(abi.F16, sc, W, H, spp, args.steps, args.warmup, rank, world, local,
+                                               not args.no_stage_timing)
+    if rank == 0:
+        win_rows = res32["window_rows"][1] - res32["window_rows"][0]
+        out = {
+            "metric": "Mray/s at 1920x1080, 4 spp (frames/s alongside), fp32 headline + fp16, Cornell-box glTF-equivalent scene",
+            "value": res32["mrays_per_s"], "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": res32["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{sc.name} {W}x{H} {spp}spp fp32 gi=on svgf=on traced-primary (BASELINE.json configs[1])",
+                       "triangles": sc.n_tris, "objects": len(sc.objects), "rays_per_frame": res32["frame_rays"],
+                       "parallelism": f"row-strips x{world} + halo {lp_dist.HALO_ROWS} + all-gather" if world > 1 else "single GPU"},
+            "frames_per_s": res32["frames_per_s"],
+            "output_finite": res32["finite"],
+            "stage_ms_per_frame": {k: v[0] / args.steps for k, v in res32["stage"].items() if v[1]},
+        }
+        if res16 is not None:
+            out["fp16"] = {"value": res16["mrays_per_s"], "unit": "Mray/s", "ms_per_step": res16["ms_per_step"],
+                           "frames_per_s": res16["frames_per_s"], "rays_per_frame": res16["frame_rays"], "dtype": "f16",
+                           "workload": f"{sc.name} {W}x{H} {spp}spp fp16 (BASELINE.json configs[2])",
+                           "speedup_vs_f32": res16["mrays_per_s"] / res32["mrays_per_s"],
+                           "stage_ms_per_frame": {k: v[0] / args.steps for k, v in res16["stage"].items() if v[1]},
+                           "roofline": roofline_of(res16, abi.F16, W * win_rows, spp) if res16["stage"] else None}
+        out["roofline"] = roofline_of(res32, abi.F32, W * win_rows, spp) if res32["stage"] else None
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sc, spp)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -192,24 +192,28 @@ typedef enum {
     LPRT_BUF_COUNT = 17
 } lprt_buffer_id;
 
-/* Per-stage GPU time of the last frame(s); labels follow the reference's GUI timer
- * (rt/gui/imgui_window.cu:154-280). */
+/* Per-kernel GPU time (HIP events on the context's stream) and work counters; one id per kernel family.
+ * The reference times the same stages on the host around cudaDeviceSynchronize
+ * (rt/gui/imgui_window.cu:86-91, labels at :154-280). */
 typedef enum {
-    LPRT_STAGE_BUILD_BLAS = 0,
-    LPRT_STAGE_BUILD_TLAS = 1,
-    LPRT_STAGE_PRIMARY = 2,
-    LPRT_STAGE_TEMPORAL_MAP = 3,
-    LPRT_STAGE_RNG = 4,
-    LPRT_STAGE_SHADE1 = 5,
-    LPRT_STAGE_TRACE_DI1 = 6,
-    LPRT_STAGE_TRACE_GI = 7,
-    LPRT_STAGE_SHADE2 = 8,
-    LPRT_STAGE_TRACE_DI2 = 9,
-    LPRT_STAGE_COMPOSE = 10,
-    LPRT_STAGE_SVGF = 11,
-    LPRT_STAGE_TAA_OUTPUT = 12,
-    LPRT_STAGE_BACKUP = 13,
-    LPRT_STAGE_COUNT = 14
+    LPRT_STAGE_BUILD_BLAS = 0,     /* all kernels of lprt_build_blas */
+    LPRT_STAGE_BUILD_TLAS = 1,     /* k_build_tlas */
+    LPRT_STAGE_PRIMARY = 2,        /* k_fill_gbuffer            "Primary Ray" */
+    LPRT_STAGE_TEMPORAL_MAP = 3,   /* k_temporal_map            "Generate Temporal Map" */
+    LPRT_STAGE_RNG = 4,            /* k_rng_expand x3 per seed  (curand_init in the reference's shade) */
+    LPRT_STAGE_SHADE1 = 5,         /* k_shade<first>            "Pixel Shade #1" */
+    LPRT_STAGE_TRACE_DI1 = 6,      /* k_trace_di<first>         "Trace DI Ray #1" + "Accumulate DI #1" */
+    LPRT_STAGE_TRACE_GI = 7,       /* k_trace_gi                "Trace GI #1" */
+    LPRT_STAGE_SHADE2 = 8,         /* k_shade<second>           "Shade #2" */
+    LPRT_STAGE_TRACE_DI2 = 9,      /* k_trace_di<second>        "Trace DI #2" + "Accumulate DI #2" */
+    LPRT_STAGE_COMPOSE = 10,       /* k_compose                 write_clean_color + spp mean */
+    LPRT_STAGE_SVGF_GRADIENT = 11, /* k_depth_gradient */
+    LPRT_STAGE_SVGF_TEMPORAL = 12, /* k_temporal_color */
+    LPRT_STAGE_SVGF_MOMENTS = 13,  /* k_moments */
+    LPRT_STAGE_SVGF_WAVELET = 14,  /* k_wavelet<1,2,4,8,16>: five launches per frame */
+    LPRT_STAGE_FINALIZE = 15,      /* k_finalize                add_denoised_color + "TAA" + output + pixel ids */
+    LPRT_STAGE_BACKUP = 16,        /* k_copy_last_transform     "Backup Temporal Data" */
+    LPRT_STAGE_COUNT = 17
 } lprt_stage_id;
 
 typedef struct lprt_ctx lprt_ctx;
@@ -278,14 +282,21 @@ int lprt_read_buffer(lprt_ctx *ctx, lprt_buffer_id id, float *dst, size_t n_floa
  * [row_end-row_begin][width][4] floats, valid until lprt_destroy. */
 int lprt_output_device_ptr(lprt_ctx *ctx, void **ptr, size_t *bytes);
 
+/* Sharded frames: besides its own output plane the context also writes image rows
+ * [first_row, first_row + n_rows) of the final RGBA32F image to dst (row-major, width*4 floats per row),
+ * e.g. this rank's slot of the tensor handed to the RCCL all-gather.  dst = NULL turns it off. */
+int lprt_set_output_target(lprt_ctx *ctx, void *dst_device, uint32_t first_row, uint32_t n_rows);
+
 /* cast_ray<find_any,false> over a host ray batch (rt/rtrt/cuda.hpp:622-631), for hit-record parity
  * and ray-rate measurement; rays are rounded to DataT on the device like a TraceGICommand. */
 int lprt_trace_rays(lprt_ctx *ctx, const lprt_ray *rays, uint32_t n_rays, int find_any,
                     lprt_hit *hits);
 
-/* Counters are collected only while enabled (instrumented kernel variants). */
+/* Counters are collected only while enabled (instrumented kernel variants). lprt_get_counters sums all
+ * stages (ray batches of lprt_trace_rays are booked under LPRT_STAGE_PRIMARY). */
 int lprt_enable_counters(lprt_ctx *ctx, int enable);
 int lprt_get_counters(lprt_ctx *ctx, lprt_counters *out);
+int lprt_get_stage_counters(lprt_ctx *ctx, lprt_stage_id stage, lprt_counters *out);
 int lprt_reset_counters(lprt_ctx *ctx);
 
 /* Per-stage HIP-event timing (ms, accumulated since the last reset) and launch counts. */
@@ -299,6 +310,10 @@ int lprt_get_blas_info(lprt_ctx *ctx, uint32_t vao_index, uint32_t *n_triangles,
                        uint32_t *depth);
 int lprt_read_blas_order(lprt_ctx *ctx, uint32_t vao_index, uint32_t *tri_order, uint32_t n);
 int lprt_read_blas_boxes(lprt_ctx *ctx, uint32_t vao_index, float *boxes6, uint32_t n_nodes);
+
+/* Test hook: xorwow state words v[0..4], d of curand_init(seed, n, 0) for global pixels n in
+ * [first, first + count), as the frame kernels receive them; out = [count][6] uint32. */
+int lprt_debug_rng_states(lprt_ctx *ctx, uint64_t seed, uint32_t first, uint32_t count, uint32_t *out);
 
 const char *lprt_version(void);
 

@@ -11,10 +11,9 @@ __version__ = "0.1.0"
 
 
 def __getattr__(name):  # lazy: keeps `import lprt_amd` usable for CPU-only host logic (scenes, abi)
+    import importlib
     if name in ("Renderer", "load_library", "LprtError", "library_path"):
-        from . import renderer
-        return getattr(renderer, name)
-    if name == "dist":
-        from . import dist
-        return dist
+        return getattr(importlib.import_module(__name__ + ".renderer"), name)
+    if name in ("dist", "renderer", "gltf"):
+        return importlib.import_module(__name__ + "." + name)
     raise AttributeError(name)

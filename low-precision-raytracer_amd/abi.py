@@ -76,7 +76,13 @@ BUF = dict(COLOR_INPROGRESS=0, MUL_GI_COLORED=1, MUL_GI_WHITE=2, INTENSITY0=3, I
 BUF_CHANNELS = {0: 3, 1: 3, 2: 3, 3: 3, 4: 3, 5: 3, 6: 4, 7: 4, 8: 4, 9: 4, 10: 4, 11: 4, 12: 1, 13: 1, 14: 3, 15: 3,
                 16: 3}
 STAGES = ["build_blas", "build_tlas", "primary", "temporal_map", "rng", "shade1", "trace_di1", "trace_gi", "shade2",
-          "trace_di2", "compose", "svgf", "taa_output", "backup"]
+          "trace_di2", "compose", "svgf_gradient", "svgf_temporal", "svgf_moments", "svgf_wavelet", "finalize", "backup"]
+# device kernel behind each stage id (the names rocprofv3 --kernel-trace reports)
+STAGE_KERNELS = {"primary": "k_fill_gbuffer", "temporal_map": "k_temporal_map", "rng": "k_rng_expand", "shade1": "k_shade",
+                 "trace_di1": "k_trace_di", "trace_gi": "k_trace_gi", "shade2": "k_shade", "trace_di2": "k_trace_di",
+                 "compose": "k_compose", "svgf_gradient": "k_depth_gradient", "svgf_temporal": "k_temporal_color",
+                 "svgf_moments": "k_moments", "svgf_wavelet": "k_wavelet", "finalize": "k_finalize",
+                 "backup": "k_copy_last_transform", "build_tlas": "k_build_tlas"}
 
 # numpy dtypes with identical layout (for bulk ray/hit arrays)
 import numpy as np

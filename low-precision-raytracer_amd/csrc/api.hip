@@ -24,7 +24,10 @@ struct CtxBase {
     virtual void set_scene(const lprt_object *, const lprt_aabb *, uint32_t, const lprt_light *, uint32_t, const lprt_camera *,
                            const float *, const lprt_skybox *) = 0;
     virtual void trace_rays(const lprt_ray *, uint32_t, int, lprt_hit *) = 0;
-    virtual void get_counters(lprt_counters *) = 0;
+    virtual void get_counters(int stage, lprt_counters *) = 0;
+    virtual void rng_states(uint64_t, uint32_t, uint32_t, uint32_t *) = 0;
+    void *ext_out = nullptr;
+    uint32_t ext_first_row = 0, ext_rows = 0;
     virtual void reset_counters() = 0;
     virtual void blas_info(uint32_t, uint32_t *, uint32_t *, uint32_t *) = 0;
     virtual void read_blas_order(uint32_t, uint32_t *, uint32_t) = 0;
@@ -102,7 +105,7 @@ template <typename T> struct Impl : CtxBase {
 
     DevBuf d_debug;
     Impl() {
-        d_counters.reserve(sizeof(Counters));
+        d_counters.reserve(sizeof(Counters) * LPRT_STAGE_COUNT);
         d_debug.reserve(64);
         LPRT_HIP(hipMemset(d_debug.ptr, 0, 64));
     }
@@ -222,14 +225,13 @@ template <typename T> struct Impl : CtxBase {
             sc.cam_L2W.m[k] = (T)camera.transform_L2W[k];
         sc.cam_fovy = (T)camera.field_of_view_y;
         sc.sky_valid = 0;
-        Counters *cnt = counters_enabled ? d_counters.as<Counters>() : nullptr;
         const uint32_t total_px = win.W * win.H, first_px = win.row_begin * win.W, npix = win.npix();
         auto seed_of = [&](uint32_t s, int which) -> uint64_t {
             if (fs.seeds)
                 return fs.seeds[3 * s + (uint32_t)which];
             return 3 * (frame_index * spp + s) + 1 + (uint64_t)which;
         };
-        stage(LPRT_STAGE_PRIMARY, [&] { launch_fill_gbuffer<T>(stream, sc, fb, cnt); });
+        stage(LPRT_STAGE_PRIMARY, [&] { launch_fill_gbuffer<T>(stream, sc, fb, stage_counters(LPRT_STAGE_PRIMARY)); });
         const bool first = frame_index == 0;
         uint32_t d_a = 0;
         if (!first)
@@ -240,27 +242,37 @@ template <typename T> struct Impl : CtxBase {
             if (fs.gi_on)
                 stage(LPRT_STAGE_RNG, [&] { d_b = rng.generate(stream, seed_of(s, 1), total_px, first_px, npix, fb.rng_state); });
             stage(LPRT_STAGE_SHADE1, [&] { launch_shade<T>(stream, sc, fb, true, !fs.gi_on, d_b); });
-            stage(LPRT_STAGE_TRACE_DI1, [&] { launch_trace_di<T>(stream, sc, fb, true, cnt); });
+            stage(LPRT_STAGE_TRACE_DI1, [&] { launch_trace_di<T>(stream, sc, fb, true, stage_counters(LPRT_STAGE_TRACE_DI1)); });
             if (fs.gi_on) {
-                stage(LPRT_STAGE_TRACE_GI, [&] { launch_trace_gi<T>(stream, sc, fb, cnt); });
+                stage(LPRT_STAGE_TRACE_GI, [&] { launch_trace_gi<T>(stream, sc, fb, stage_counters(LPRT_STAGE_TRACE_GI)); });
                 stage(LPRT_STAGE_SHADE2, [&] { launch_shade<T>(stream, sc, fb, false, true, 0u); });
-                stage(LPRT_STAGE_TRACE_DI2, [&] { launch_trace_di<T>(stream, sc, fb, false, cnt); });
+                stage(LPRT_STAGE_TRACE_DI2, [&] { launch_trace_di<T>(stream, sc, fb, false, stage_counters(LPRT_STAGE_TRACE_DI2)); });
             }
             stage(LPRT_STAGE_COMPOSE, [&] { launch_compose<T>(stream, fb, fs.gi_on != 0, fs.add_direct_out != 0, s, spp); });
         }
         const V4<T> *res0 = fb.lobe[0].cv_a, *res1 = fb.lobe[1].cv_a;
         svgf_ran = fs.svgf != 0;
         if (fs.svgf) {
-            stage(LPRT_STAGE_SVGF, [&] { launch_svgf<T>(stream, fb, fs.svgf_color_mix_weight, fs.svgf_moments_mix_weight); });
+            // svgf_denoise (cuda.hpp:1636-1711), both lobes per launch
+            stage(LPRT_STAGE_SVGF_GRADIENT, [&] { launch_depth_gradient<T>(stream, fb); });
+            stage(LPRT_STAGE_SVGF_TEMPORAL, [&] { launch_temporal_color<T>(stream, fb, fs.svgf_color_mix_weight); });
+            stage(LPRT_STAGE_SVGF_MOMENTS, [&] { launch_moments<T>(stream, fb, fs.svgf_moments_mix_weight); });
+            for (int level = 0; level < 5; level++)
+                stage(LPRT_STAGE_SVGF_WAVELET, [&] { launch_wavelet<T>(stream, fb, level); });
+            // moments history for the next frame: swap instead of the reference's (short) memcpy (DEVIATION Q8)
+            for (int l = 0; l < 2; l++) {
+                std::swap(fb.lobe[l].miu1_hist, fb.lobe[l].miu1_cur);
+                std::swap(fb.lobe[l].miu2_hist, fb.lobe[l].miu2_cur);
+            }
             res0 = fb.lobe[0].cv_c;
             res1 = fb.lobe[1].cv_c;
         }
         V4<T> *taa_next = (fb.taa_history == taa_a) ? taa_b : taa_a;
-        // last_frame_transform_W2C as used by THIS frame's temporal map was set at the end of the previous frame
-        stage(LPRT_STAGE_TAA_OUTPUT, [&] {
+        stage(LPRT_STAGE_FINALIZE, [&] {
             launch_finalize<T>(stream, sc, fb, res0, res1, taa_next, fs.add_gi_colored != 0, fs.add_gi_white != 0, fs.demodulate != 0,
-                               fs.taa_mix_weight, n_objects);
+                               fs.taa_mix_weight, static_cast<float4 *>(ext_out), ext_first_row, ext_rows);
         });
+        stage(LPRT_STAGE_BACKUP, [&] { launch_copy_last_transform<T>(stream, sc, fb.last_frame_L2W, n_objects); });
         fb.taa_history = taa_next;
         for (int k = 0; k < 16; k++)
             fb.last_frame_W2C.m[k] = (T)w2c[k]; // buffer->last_frame_transform_W2C = render_data->transform_W2C (imgui_window.cu:277)
@@ -332,7 +344,9 @@ template <typename T> struct Impl : CtxBase {
             launch_convert_materials<T>(stream, d_materials32.as<lprt_material>(), d_materials.as<MaterialT<T>>(), n);
         }
     }
-    void build_blas() override { geo.build_blas(stream); }
+    void build_blas() override {
+        stage(LPRT_STAGE_BUILD_BLAS, [&] { geo.build_blas(stream); });
+    }
     void set_scene(const lprt_object *obj, const lprt_aabb *aabbs, uint32_t n, const lprt_light *lights, uint32_t nl,
                    const lprt_camera *cam, const float *W2C, const lprt_skybox *sky) override {
         n_objects = n;
@@ -345,7 +359,7 @@ template <typename T> struct Impl : CtxBase {
             LPRT_HIP(hipMemcpyAsync(d_objects32.ptr, obj, sizeof(lprt_object) * (size_t)n, hipMemcpyHostToDevice, stream));
         if (nl)
             LPRT_HIP(hipMemcpyAsync(d_lights32.ptr, lights, sizeof(lprt_light) * (size_t)nl, hipMemcpyHostToDevice, stream));
-        tlas.build(stream, aabbs, n);
+        stage(LPRT_STAGE_BUILD_TLAS, [&] { tlas.build(stream, aabbs, n); });
         LPRT_HIP(hipStreamSynchronize(stream)); // the caller's arrays may go away after return (pageable copies)
         launch_convert_objects<T>(stream, d_objects32.as<lprt_object>(), d_objects.as<ObjConst<T>>(), n);
         launch_convert_lights<T>(stream, d_lights32.as<lprt_light>(), d_lights.as<LightT<T>>(), nl);
@@ -404,15 +418,28 @@ template <typename T> struct Impl : CtxBase {
         d_hits.reserve(sizeof(lprt_hit) * (size_t)n);
         LPRT_HIP(hipMemcpyAsync(d_rays.ptr, rays, sizeof(lprt_ray) * (size_t)n, hipMemcpyHostToDevice, stream));
         launch_trace_rays<T>(stream, scene_dev(), d_rays.as<lprt_ray>(), n, find_any != 0, d_hits.as<lprt_hit>(),
-                             counters_enabled ? d_counters.as<Counters>() : nullptr);
+                             stage_counters(LPRT_STAGE_PRIMARY));
         LPRT_HIP(hipGetLastError());
         LPRT_HIP(hipMemcpyAsync(hits, d_hits.ptr, sizeof(lprt_hit) * (size_t)n, hipMemcpyDeviceToHost, stream));
         LPRT_HIP(hipStreamSynchronize(stream));
     }
-    void get_counters(lprt_counters *out) override {
-        Counters c;
-        LPRT_HIP(hipMemcpyAsync(&c, d_counters.ptr, sizeof(c), hipMemcpyDeviceToHost, stream));
+    // stage < 0: sum over all stages
+    void get_counters(int stage, lprt_counters *out) override {
+        Counters all[LPRT_STAGE_COUNT];
+        LPRT_HIP(hipMemcpyAsync(all, d_counters.ptr, sizeof(all), hipMemcpyDeviceToHost, stream));
         LPRT_HIP(hipStreamSynchronize(stream));
+        Counters c{};
+        for (int i = 0; i < LPRT_STAGE_COUNT; i++) {
+            if (stage >= 0 && i != stage)
+                continue;
+            c.rays += all[i].rays;
+            c.tlas_nodes += all[i].tlas_nodes;
+            c.aabbw += all[i].aabbw;
+            c.objects += all[i].objects;
+            c.blas_nodes += all[i].blas_nodes;
+            c.tris += all[i].tris;
+            c.fallbacks += all[i].fallbacks;
+        }
         out->rays = c.rays;
         out->tlas_node_visits = c.tlas_nodes;
         out->aabbw_tests = c.aabbw;
@@ -421,7 +448,25 @@ template <typename T> struct Impl : CtxBase {
         out->tri_tests = c.tris;
         out->fallback_tests = c.fallbacks;
     }
-    void reset_counters() override { LPRT_HIP(hipMemsetAsync(d_counters.ptr, 0, sizeof(Counters), stream)); }
+    void reset_counters() override { LPRT_HIP(hipMemsetAsync(d_counters.ptr, 0, sizeof(Counters) * LPRT_STAGE_COUNT, stream)); }
+    Counters *stage_counters(int stage) { return counters_enabled ? d_counters.as<Counters>() + stage : nullptr; }
+    void rng_states(uint64_t seed, uint32_t first, uint32_t count, uint32_t *out) override {
+        if (!rng.ready)
+            rng.init(stream);
+        if ((uint64_t)first + count > (uint64_t)win.W * win.H || count == 0)
+            throw std::string("rng_states: pixel range outside the frame");
+        DevBuf planes;
+        planes.reserve(sizeof(uint32_t) * 5 * (size_t)count);
+        uint32_t d = rng.generate(stream, seed, win.W * win.H, first, count, planes.as<uint32_t>());
+        std::vector<uint32_t> host(5 * (size_t)count);
+        LPRT_HIP(hipMemcpyAsync(host.data(), planes.ptr, sizeof(uint32_t) * host.size(), hipMemcpyDeviceToHost, stream));
+        LPRT_HIP(hipStreamSynchronize(stream));
+        for (uint32_t i = 0; i < count; i++) {
+            for (int k = 0; k < 5; k++)
+                out[6 * (size_t)i + k] = host[(size_t)k * count + i];
+            out[6 * (size_t)i + 5] = d;
+        }
+    }
     void blas_info(uint32_t vao, uint32_t *n_tris, uint32_t *n_nodes, uint32_t *depth) override {
         if (vao >= geo.n_vaos)
             throw std::string("vao index out of range");
@@ -644,7 +689,34 @@ int lprt_enable_counters(lprt_ctx *ctx, int enable) {
     return guarded(ctx, [&](CtxBase &c) { c.counters_enabled = enable != 0; });
 }
 int lprt_get_counters(lprt_ctx *ctx, lprt_counters *out) {
-    return guarded(ctx, [&](CtxBase &c) { c.get_counters(out); });
+    return guarded(ctx, [&](CtxBase &c) {
+        if (!out)
+            throw std::string("null out pointer");
+        c.get_counters(-1, out);
+    });
+}
+int lprt_get_stage_counters(lprt_ctx *ctx, lprt_stage_id stage, lprt_counters *out) {
+    return guarded(ctx, [&](CtxBase &c) {
+        if (!out || (int)stage < 0 || (int)stage >= LPRT_STAGE_COUNT)
+            throw std::string("bad stage id or null out pointer");
+        c.get_counters((int)stage, out);
+    });
+}
+int lprt_set_output_target(lprt_ctx *ctx, void *dst, uint32_t first_row, uint32_t n_rows) {
+    return guarded(ctx, [&](CtxBase &c) {
+        if (dst && (first_row < c.win.row_begin || (uint64_t)first_row + n_rows > c.win.row_end))
+            throw std::string("output target rows must lie inside this context's row window");
+        c.ext_out = dst;
+        c.ext_first_row = first_row;
+        c.ext_rows = dst ? n_rows : 0;
+    });
+}
+int lprt_debug_rng_states(lprt_ctx *ctx, uint64_t seed, uint32_t first, uint32_t count, uint32_t *out) {
+    return guarded(ctx, [&](CtxBase &c) {
+        if (!out)
+            throw std::string("null out pointer");
+        c.rng_states(seed, first, count, out);
+    });
 }
 int lprt_reset_counters(lprt_ctx *ctx) {
     return guarded(ctx, [&](CtxBase &c) { c.reset_counters(); });

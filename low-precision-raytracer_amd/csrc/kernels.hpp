@@ -22,10 +22,14 @@ template <typename T> void launch_trace_gi(hipStream_t st, const SceneDev<T> &sc
 template <typename T> void launch_compose(hipStream_t st, const FrameDev<T> &fb, bool gi_on, bool add_direct, uint32_t sample, uint32_t spp);
 
 // svgf.hip
-template <typename T> void launch_svgf(hipStream_t st, FrameDev<T> &fb, float color_w, float moments_w);
+template <typename T> void launch_depth_gradient(hipStream_t st, const FrameDev<T> &fb);
+template <typename T> void launch_temporal_color(hipStream_t st, const FrameDev<T> &fb, float color_w);
+template <typename T> void launch_moments(hipStream_t st, const FrameDev<T> &fb, float moments_w);
+template <typename T> void launch_wavelet(hipStream_t st, const FrameDev<T> &fb, int level);
 template <typename T>
-void launch_finalize(hipStream_t st, const SceneDev<T> &sc, FrameDev<T> &fb, const V4<T> *gi_colored, const V4<T> *gi_white, V4<T> *taa_next,
-                     bool add_colored, bool add_white, bool demodulate, float taa_w, uint32_t n_objects);
+void launch_finalize(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, const V4<T> *gi_colored, const V4<T> *gi_white, V4<T> *taa_next,
+                     bool add_colored, bool add_white, bool demodulate, float taa_w, float4 *ext_out, uint32_t ext_first_row, uint32_t ext_rows);
+template <typename T> void launch_copy_last_transform(hipStream_t st, const SceneDev<T> &sc, M4<T> *last_L2W, uint32_t n_objects);
 template <typename T> void launch_read_v4(hipStream_t st, const V4<T> *src, float *dst, uint32_t n, int channels);
 void launch_read_u32(hipStream_t st, const uint32_t *src, float *dst, uint32_t n, bool rgba8);
 

@@ -11,6 +11,7 @@
 // instead of ~16 dependent matvecs with per-lane matrices.
 #include "kernels.hpp"
 #include <mutex>
+#include <string>
 
 namespace lprt {
 
@@ -20,8 +21,13 @@ struct XorMat {
 };
 
 // dst[(s*64 + j) - dst_first] = P[j] * src[s].  One block = 64 consecutive s x 16 consecutive j; a wave owns 4 j.
-__global__ void __launch_bounds__(256) k_rng_expand(const XorMat *__restrict__ P, const uint32_t *__restrict__ src, uint32_t n_src, uint32_t src_stride,
-                                                    uint32_t *__restrict__ dst, uint32_t dst_first, uint32_t dst_count, uint32_t dst_stride) {
+struct TopVectors { // level-3 source vectors (host-computed, <= 64 of them), passed by value: no copy, no sync
+    uint32_t v[5][64];
+};
+template <bool FROM_ARGS>
+__global__ void __launch_bounds__(256) k_rng_expand(const XorMat *__restrict__ P, const uint32_t *__restrict__ src, TopVectors top, uint32_t n_src,
+                                                    uint32_t src_stride, uint32_t *__restrict__ dst, uint32_t dst_first, uint32_t dst_count,
+                                                    uint32_t dst_stride) {
     __shared__ uint32_t tile[5][64][17];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t s = blockIdx.x * 64 + lane;
@@ -29,7 +35,7 @@ __global__ void __launch_bounds__(256) k_rng_expand(const XorMat *__restrict__ P
     uint32_t v[5] = {0, 0, 0, 0, 0};
     if (s < n_src)
         for (int k = 0; k < 5; k++)
-            v[k] = src[k * src_stride + s];
+            v[k] = FROM_ARGS ? top.v[k][s & 63] : src[k * src_stride + s];
     for (uint32_t jj = 0; jj < 4; jj++) {
         const uint32_t jl = wave * 4 + jj; // 0..15 within the block
         const uint32_t j = __builtin_amdgcn_readfirstlane(jbase + jl);
@@ -162,27 +168,26 @@ uint32_t RngStore::generate(hipStream_t st, uint64_t seed, uint32_t total_pixels
     uint32_t v[5] = {123456789u + t0, 362436069u ^ t0, 521288629u + t1, 88675123u ^ t1, 5783321u + t0};
     const Tables &t = tables();
     const uint32_t n1 = (total_pixels + 63) / 64, n2 = (n1 + 63) / 64, n3 = (n2 + 63) / 64;
-    // level-3 vectors on the host, SoA [5][n3]
-    std::vector<uint32_t> w3(5 * (size_t)n3);
+    // level-3 vectors on the host, handed to the first expansion as kernel arguments
+    if (n3 > 64)
+        throw std::string("frame too large for the RNG expansion (more than 2^24 pixels)");
+    TopVectors top{};
     for (uint32_t j = 0; j < n3; j++) {
         for (int k = 0; k < 5; k++)
-            w3[k * n3 + j] = v[k];
+            top.v[k][j] = v[k];
         h_apply(t.m_top, v, v);
     }
-    d_w3.reserve(sizeof(uint32_t) * w3.size());
     d_w2.reserve(sizeof(uint32_t) * 5 * (size_t)n3 * 64);
     d_w1.reserve(sizeof(uint32_t) * 5 * (size_t)n2 * 64);
-    LPRT_HIP(hipMemcpyAsync(d_w3.ptr, w3.data(), sizeof(uint32_t) * w3.size(), hipMemcpyHostToDevice, st));
-    LPRT_HIP(hipStreamSynchronize(st)); // w3 is a stack-lifetime staging buffer
     const XorMat *mats = d_mats.as<XorMat>();
-    hipLaunchKernelGGL(k_rng_expand, dim3((n3 + 63) / 64, 4), dim3(256), 0, st, mats + 128, d_w3.as<uint32_t>(), n3, n3, d_w2.as<uint32_t>(), 0u,
-                       n3 * 64, n3 * 64);
-    hipLaunchKernelGGL(k_rng_expand, dim3((n2 + 63) / 64, 4), dim3(256), 0, st, mats + 64, d_w2.as<uint32_t>(), n2, n3 * 64, d_w1.as<uint32_t>(), 0u,
-                       n2 * 64, n2 * 64);
+    hipLaunchKernelGGL(k_rng_expand<true>, dim3((n3 + 63) / 64, 4), dim3(256), 0, st, mats + 128, (const uint32_t *)nullptr, top, n3, n3,
+                       d_w2.as<uint32_t>(), 0u, n3 * 64, n3 * 64);
+    hipLaunchKernelGGL(k_rng_expand<false>, dim3((n2 + 63) / 64, 4), dim3(256), 0, st, mats + 64, d_w2.as<uint32_t>(), top, n2, n3 * 64,
+                       d_w1.as<uint32_t>(), 0u, n2 * 64, n2 * 64);
     // last level only for the L1 vectors that cover [first, first + count)
     const uint32_t s_begin = first / 64, s_end = (first + count + 63) / 64;
-    hipLaunchKernelGGL(k_rng_expand, dim3((s_end - s_begin + 63) / 64, 4), dim3(256), 0, st, mats, d_w1.as<uint32_t>() + s_begin, s_end - s_begin,
-                       n2 * 64, planes, first - s_begin * 64, count, count);
+    hipLaunchKernelGGL(k_rng_expand<false>, dim3((s_end - s_begin + 63) / 64, 4), dim3(256), 0, st, mats, d_w1.as<uint32_t>() + s_begin, top,
+                       s_end - s_begin, n2 * 64, planes, first - s_begin * 64, count, count);
     LPRT_HIP(hipGetLastError());
     return d;
 }

@@ -276,7 +276,8 @@ __global__ void __launch_bounds__(256) k_wavelet(FrameDev<T> fb, const V4<T> *in
 // ---- add_denoised_color + temporal_anti_aliasing + write_to_surface2d + copy_last_frame_pixel_id ---------------------
 template <typename T>
 __global__ void __launch_bounds__(256) k_finalize(SceneDev<T> sc, FrameDev<T> fb, const V4<T> *gi_colored, const V4<T> *gi_white,
-                                                  V4<T> *taa_next, int add_colored, int add_white, int demodulate, T taa_w) {
+                                                  V4<T> *taa_next, int add_colored, int add_white, int demodulate, T taa_w, float4 *ext_out,
+                                                  uint32_t ext_first_row, uint32_t ext_rows) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= fb.win.npix())
         return;
@@ -295,7 +296,13 @@ __global__ void __launch_bounds__(256) k_finalize(SceneDev<T> sc, FrameDev<T> fb
     fb.color_inprogress[p] = o4;
     taa_next[p] = o4; // history for the next frame (imgui_window.cu:260-262), double-buffered
     const float ig = 1 / 2.2f;
-    fb.output[p] = make_float4(::powf((float)out.x, ig), ::powf((float)out.y, ig), ::powf((float)out.z, ig), 1.f);
+    const float4 rgba = make_float4(::powf((float)out.x, ig), ::powf((float)out.y, ig), ::powf((float)out.z, ig), 1.f);
+    fb.output[p] = rgba;
+    if (ext_out) { // this rank's rows of the gathered frame (sharded rendering)
+        const uint32_t row = fb.win.row_begin + p / fb.win.W;
+        if (row >= ext_first_row && row - ext_first_row < ext_rows)
+            ext_out[(size_t)(row - ext_first_row) * fb.win.W + p % fb.win.W] = rgba;
+    }
     // copy_last_frame_pixel_id (cuda.hpp:2230-2251)
     uint2 id;
     if ((fb.g_color[p] >> 24) == 0) {
@@ -341,33 +348,37 @@ __global__ void k_read_u32(const uint32_t *src, float *dst, uint32_t n, int rgba
 // ---- launchers -------------------------------------------------------------------------------------------------------
 static inline dim3 grid_for(uint32_t n) { return dim3((n + 255) / 256); }
 
-template <typename T> void launch_svgf(hipStream_t st, FrameDev<T> &fb, float color_w, float moments_w) {
+template <typename T> void launch_depth_gradient(hipStream_t st, const FrameDev<T> &fb) {
+    hipLaunchKernelGGL(k_depth_gradient<T>, grid_for(fb.win.npix()), dim3(256), 0, st, fb);
+}
+template <typename T> void launch_temporal_color(hipStream_t st, const FrameDev<T> &fb, float color_w) {
+    hipLaunchKernelGGL(k_temporal_color<T>, grid_for(fb.win.npix()), dim3(256), 0, st, fb, (T)color_w);
+}
+template <typename T> void launch_moments(hipStream_t st, const FrameDev<T> &fb, float moments_w) {
+    hipLaunchKernelGGL(k_moments<T>, grid_for(fb.win.npix()), dim3(256), 0, st, fb, (T)moments_w);
+}
+// level = 0..4 -> stride 1,2,4,8,16.  Buffer rotation (cuda.hpp:1678-1710 with cv_c in the role of color_inout, which
+// holds the integrated colour): L1 c->b (b = next frame's history), L2 b->a, L3 a->c, L4 c->a, L5 a->c; result in cv_c.
+template <typename T> void launch_wavelet(hipStream_t st, const FrameDev<T> &fb, int level) {
     const dim3 g = grid_for(fb.win.npix()), b(256);
-    auto to_T = [](float f) { return (T)f; };
-    hipLaunchKernelGGL(k_depth_gradient<T>, g, b, 0, st, fb);
-    hipLaunchKernelGGL(k_temporal_color<T>, g, b, 0, st, fb, to_T(color_w));
-    hipLaunchKernelGGL(k_moments<T>, g, b, 0, st, fb, to_T(moments_w));
-    SvgfLobe<T> &a = fb.lobe[0], &w = fb.lobe[1];
-    // integrated colour is in cv_c.  Rotation (cuda.hpp:1678-1710 with cv_c in the role of color_inout):
-    // L1 c->b (b = next frame's history), L2 b->a, L3 a->c, L4 c->a, L5 a->c; result in cv_c.
-    hipLaunchKernelGGL((k_wavelet<T, 1>), g, b, 0, st, fb, a.cv_c, a.cv_b, w.cv_c, w.cv_b);
-    hipLaunchKernelGGL((k_wavelet<T, 2>), g, b, 0, st, fb, a.cv_b, a.cv_a, w.cv_b, w.cv_a);
-    hipLaunchKernelGGL((k_wavelet<T, 4>), g, b, 0, st, fb, a.cv_a, a.cv_c, w.cv_a, w.cv_c);
-    hipLaunchKernelGGL((k_wavelet<T, 8>), g, b, 0, st, fb, a.cv_c, a.cv_a, w.cv_c, w.cv_a);
-    hipLaunchKernelGGL((k_wavelet<T, 16>), g, b, 0, st, fb, a.cv_a, a.cv_c, w.cv_a, w.cv_c);
-    // moments history for the next frame: swap instead of the reference's (short) memcpy (DEVIATION Q8)
-    for (int l = 0; l < 2; l++) {
-        std::swap(fb.lobe[l].miu1_hist, fb.lobe[l].miu1_cur);
-        std::swap(fb.lobe[l].miu2_hist, fb.lobe[l].miu2_cur);
+    const SvgfLobe<T> &a = fb.lobe[0], &w = fb.lobe[1];
+    switch (level) {
+    case 0: hipLaunchKernelGGL((k_wavelet<T, 1>), g, b, 0, st, fb, a.cv_c, a.cv_b, w.cv_c, w.cv_b); break;
+    case 1: hipLaunchKernelGGL((k_wavelet<T, 2>), g, b, 0, st, fb, a.cv_b, a.cv_a, w.cv_b, w.cv_a); break;
+    case 2: hipLaunchKernelGGL((k_wavelet<T, 4>), g, b, 0, st, fb, a.cv_a, a.cv_c, w.cv_a, w.cv_c); break;
+    case 3: hipLaunchKernelGGL((k_wavelet<T, 8>), g, b, 0, st, fb, a.cv_c, a.cv_a, w.cv_c, w.cv_a); break;
+    default: hipLaunchKernelGGL((k_wavelet<T, 16>), g, b, 0, st, fb, a.cv_a, a.cv_c, w.cv_a, w.cv_c); break;
     }
 }
 template <typename T>
-void launch_finalize(hipStream_t st, const SceneDev<T> &sc, FrameDev<T> &fb, const V4<T> *gi_colored, const V4<T> *gi_white, V4<T> *taa_next,
-                     bool add_colored, bool add_white, bool demodulate, float taa_w, uint32_t n_objects) {
+void launch_finalize(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, const V4<T> *gi_colored, const V4<T> *gi_white, V4<T> *taa_next,
+                     bool add_colored, bool add_white, bool demodulate, float taa_w, float4 *ext_out, uint32_t ext_first_row, uint32_t ext_rows) {
     hipLaunchKernelGGL(k_finalize<T>, grid_for(fb.win.npix()), dim3(256), 0, st, sc, fb, gi_colored, gi_white, taa_next, add_colored ? 1 : 0,
-                       add_white ? 1 : 0, demodulate ? 1 : 0, (T)taa_w);
+                       add_white ? 1 : 0, demodulate ? 1 : 0, (T)taa_w, ext_out, ext_first_row, ext_rows);
+}
+template <typename T> void launch_copy_last_transform(hipStream_t st, const SceneDev<T> &sc, M4<T> *last_L2W, uint32_t n_objects) {
     if (n_objects)
-        hipLaunchKernelGGL(k_copy_last_transform<T>, dim3((n_objects + 63) / 64), dim3(64), 0, st, sc, fb.last_frame_L2W, n_objects);
+        hipLaunchKernelGGL(k_copy_last_transform<T>, dim3((n_objects + 63) / 64), dim3(64), 0, st, sc, last_L2W, n_objects);
 }
 template <typename T> void launch_read_v4(hipStream_t st, const V4<T> *src, float *dst, uint32_t n, int channels) {
     hipLaunchKernelGGL(k_read_v4<T>, grid_for(n), dim3(256), 0, st, src, dst, n, channels);
@@ -377,9 +388,13 @@ void launch_read_u32(hipStream_t st, const uint32_t *src, float *dst, uint32_t n
 }
 
 #define INST(T)                                                                                                        \
-    template void launch_svgf<T>(hipStream_t, FrameDev<T> &, float, float);                                            \
-    template void launch_finalize<T>(hipStream_t, const SceneDev<T> &, FrameDev<T> &, const V4<T> *, const V4<T> *,    \
-                                     V4<T> *, bool, bool, bool, float, uint32_t);                                      \
+    template void launch_depth_gradient<T>(hipStream_t, const FrameDev<T> &);                                          \
+    template void launch_temporal_color<T>(hipStream_t, const FrameDev<T> &, float);                                   \
+    template void launch_moments<T>(hipStream_t, const FrameDev<T> &, float);                                          \
+    template void launch_wavelet<T>(hipStream_t, const FrameDev<T> &, int);                                            \
+    template void launch_finalize<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, const V4<T> *,             \
+                                     const V4<T> *, V4<T> *, bool, bool, bool, float, float4 *, uint32_t, uint32_t);  \
+    template void launch_copy_last_transform<T>(hipStream_t, const SceneDev<T> &, M4<T> *, uint32_t);                  \
     template void launch_read_v4<T>(hipStream_t, const V4<T> *, float *, uint32_t, int);
 INST(float)
 INST(h16)

@@ -1,0 +1,79 @@
+"""Frame sharding across the GPUs of one node.
+
+Every pixel is independent up to the denoiser, and the RNG is keyed by the GLOBAL pixel index, so a frame is cut
+into row strips: rank r renders rows [r*H/N, (r+1)*H/N) plus a halo of HALO_ROWS on each side (the reach of the
+SVGF stencils), denoises locally, and writes only its own rows into its slot of the gathered image; one
+all-gather (RCCL over xGMI through torch.distributed, backend "nccl") completes the frame on every rank.  Scene
+data (geometry, BVH, materials) is replicated.  There is no other exchange on the data path.
+"""
+import numpy as np
+
+# a-trous reach 2*(1+2+4+8+16) = 62, + 1 (3x3 variance / gradient) + 4 (9x9 clamp) = 67 rows
+HALO_ROWS = 67
+
+
+def strip_rows(height, world_size, rank):
+    """Rows [begin, end) owned by `rank`: contiguous, near-equal strips (row-major => all-gather lands in place)."""
+    base, rem = divmod(height, world_size)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def window_rows(height, world_size, rank, halo=HALO_ROWS):
+    """Rows [begin, end) a rank RENDERS: its strip plus the halo, clipped to the image."""
+    b, e = strip_rows(height, world_size, rank)
+    return max(0, b - halo), min(height, e + halo)
+
+
+def equal_strips(height, world_size):
+    """all_gather_into_tensor needs equal counts per rank."""
+    return height % world_size == 0
+
+
+class ShardedFrame:
+    """Owns the gathered RGBA32F image of one rank and performs the per-frame all-gather."""
+
+    def __init__(self, width, height, rank, world_size, device):
+        import torch
+        self.torch = torch
+        self.W, self.H, self.rank, self.world = width, height, rank, world_size
+        self.device = device
+        self.begin, self.end = strip_rows(height, world_size, rank)
+        self.win_begin, self.win_end = window_rows(height, world_size, rank)
+        self.image = torch.zeros((height, width, 4), dtype=torch.float32, device=device)
+        self.equal = equal_strips(height, world_size)
+        if not self.equal:  # ragged strips: gather through padded per-rank buffers
+            self.max_rows = -(-height // world_size)
+            self.send = torch.zeros((self.max_rows, width, 4), dtype=torch.float32, device=device)
+            self.recv = torch.zeros((world_size, self.max_rows, width, 4), dtype=torch.float32, device=device)
+
+    def target(self):
+        """(device pointer, first_row, n_rows) for lprt_set_output_target."""
+        if self.equal:
+            return self.image[self.begin:self.end].data_ptr(), self.begin, self.end - self.begin
+        return self.send.data_ptr(), self.begin, self.end - self.begin
+
+    def all_gather(self):
+        import torch.distributed as dist
+        if self.world == 1:
+            return self.image
+        if self.equal:
+            dist.all_gather_into_tensor(self.image.view(-1), self.image[self.begin:self.end].reshape(-1))
+        else:
+            dist.all_gather_into_tensor(self.recv.view(-1), self.send.view(-1))
+            for r in range(self.world):
+                b, e = strip_rows(self.H, self.world, r)
+                self.image[b:e].copy_(self.recv[r, :e - b])
+        return self.image
+
+
+def assemble_strips(strips, height, world_size):
+    """CPU helper (tests): stitch per-rank strips (numpy [rows, W, C]) into the full frame."""
+    out = None
+    for r, s in enumerate(strips):
+        b, e = strip_rows(height, world_size, r)
+        assert s.shape[0] == e - b
+        if out is None:
+            out = np.zeros((height,) + s.shape[1:], dtype=s.dtype)
+        out[b:e] = s
+    return out

@@ -43,7 +43,10 @@ SYMBOLS = [
     ("lprt_trace_rays", C.c_int, [_P, _P, C.c_uint32, C.c_int, _P]),
     ("lprt_enable_counters", C.c_int, [_P, C.c_int]),
     ("lprt_get_counters", C.c_int, [_P, _P]),
+    ("lprt_get_stage_counters", C.c_int, [_P, C.c_int, _P]),
     ("lprt_reset_counters", C.c_int, [_P]),
+    ("lprt_set_output_target", C.c_int, [_P, _P, C.c_uint32, C.c_uint32]),
+    ("lprt_debug_rng_states", C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_uint32, _P]),
     ("lprt_enable_stage_timing", C.c_int, [_P, C.c_int]),
     ("lprt_get_stage_times", C.c_int, [_P, _P, _P]),
     ("lprt_reset_stage_times", C.c_int, [_P]),
@@ -184,6 +187,21 @@ class Renderer:
 
     def reset_counters(self):
         self._check(self.L.lprt_reset_counters(self.h), "lprt_reset_counters")
+
+    def stage_counters(self, stage):
+        c = abi.Counters()
+        sid = abi.STAGES.index(stage) if isinstance(stage, str) else stage
+        self._check(self.L.lprt_get_stage_counters(self.h, sid, C.byref(c)), "lprt_get_stage_counters")
+        return c.as_dict()
+
+    def set_output_target(self, dev_ptr, first_row, n_rows):
+        self._check(self.L.lprt_set_output_target(self.h, C.c_void_p(int(dev_ptr) if dev_ptr else 0), first_row, n_rows),
+                    "lprt_set_output_target")
+
+    def rng_states(self, seed, first, count):
+        out = np.zeros((count, 6), dtype=np.uint32)
+        self._check(self.L.lprt_debug_rng_states(self.h, int(seed), first, count, _ptr(out)), "lprt_debug_rng_states")
+        return out
 
     def enable_stage_timing(self, on=True):
         self._check(self.L.lprt_enable_stage_timing(self.h, int(on)), "lprt_enable_stage_timing")

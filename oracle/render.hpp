@@ -1594,7 +1594,7 @@ template <typename T> class Renderer {
             if (fs.add_gi_white)
                 color_inprogress[i] += mul_gi_white[i];
         }
-        stage_seconds[LPRT_STAGE_SVGF] += tm.lap();
+        stage_seconds[LPRT_STAGE_SVGF_WAVELET] += tm.lap(); // whole SVGF + add_denoised_color
         // temporal_anti_aliasing (cuda.hpp:2418-2439) + write_to_surface2d (cuda.hpp:2441-2455)
         T taa_w = T(fs.taa_mix_weight);
         for (size_t i = 0; i < N; i++) {
@@ -1607,7 +1607,7 @@ template <typename T> class Renderer {
             output[i][3] = 1.f;
         }
         taa_history_color = color_inprogress;
-        stage_seconds[LPRT_STAGE_TAA_OUTPUT] += tm.lap();
+        stage_seconds[LPRT_STAGE_FINALIZE] += tm.lap();
         // copy_last_frame_pixel_id / copy_last_frame_transform (cuda.hpp:2230-2263)
         for (size_t i = 0; i < N; i++) {
             if (g_color[i][3] == 0) {

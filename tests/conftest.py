@@ -1,0 +1,58 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this environment")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def cornell():
+    import lprt_amd  # noqa: F401
+    from lprt_amd import scenes
+    return scenes.cornell_box()
+
+
+@pytest.fixture(scope="session")
+def small_scene():
+    import lprt_amd  # noqa: F401
+    from lprt_amd import scenes
+    return scenes.small_test_scene()
+
+
+@pytest.fixture(scope="session")
+def sponza():
+    import lprt_amd  # noqa: F401
+    from lprt_amd import scenes
+    return scenes.sponza_like()
+
+
+def rel_l2(a, b):
+    import numpy as np
+    a = np.nan_to_num(np.asarray(a, dtype=np.float64), nan=0.0, posinf=0.0, neginf=0.0)
+    b = np.nan_to_num(np.asarray(b, dtype=np.float64), nan=0.0, posinf=0.0, neginf=0.0)
+    den = np.linalg.norm(b)
+    return float(np.linalg.norm(a - b) / den) if den > 0 else float(np.linalg.norm(a - b))

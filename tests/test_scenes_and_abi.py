@@ -1,0 +1,95 @@
+"""Host logic: scene generators, struct layouts against the C header, exported symbols of the HIP library."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import numpy as np
+
+import lprt_amd
+from lprt_amd import abi, scenes, renderer, dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "lprt.h")
+
+
+def test_cornell_box_matches_the_survey_spec(cornell):
+    assert cornell.n_tris == 36 and len(cornell.objects) == 8 and len(cornell.materials) == 6
+    assert len(cornell.lights) == 1 and cornell.lights[0]["type"] == abi.LIGHT_POINT
+    assert np.abs(cornell.vertices["position"]).max() <= 1.0 + 1e-6  # local coordinates, fp16-safe
+    assert np.allclose(np.linalg.norm(cornell.vertices["normal"], axis=1), 1.0, atol=1e-6)
+    t, n = cornell.vertices["tangent"], cornell.vertices["normal"]
+    assert np.allclose((t * n).sum(axis=1), 0.0, atol=1e-6)  # synthesised tangents are perpendicular (loader.cu:376-389)
+    for o, a in zip(cornell.objects, cornell.aabbs):
+        assert np.allclose(o["L2W"].astype(np.float64) @ o["W2L"].astype(np.float64), np.eye(4), atol=1e-5)
+        assert (a[:3] <= a[3:]).all()
+
+
+def test_sponza_like_matches_the_survey_spec(sponza):
+    assert abs(sponza.n_tris - 262144) <= 2621 and len(sponza.vaos) == 24 and len(sponza.materials) == 12
+    assert [l["type"] for l in sponza.lights] == [abi.LIGHT_DIRECTIONAL, abi.LIGHT_POINT, abi.LIGHT_POINT]
+    ends = sponza.vaos[:, 2] + sponza.vaos[:, 3]
+    assert (sponza.vaos[1:, 2] == ends[:-1]).all() and ends[-1] == len(sponza.indices)
+    assert sponza.indices.max() < len(sponza.vertices)
+    again = scenes.sponza_like()
+    assert np.array_equal(again.indices, sponza.indices) and np.array_equal(again.vertices, sponza.vertices)
+
+
+def test_ctypes_structs_match_the_c_header():
+    fields = {
+        "lprt_vertex": abi.Vertex, "lprt_mesh_vao": abi.MeshVAO, "lprt_material": abi.Material, "lprt_object": abi.Object,
+        "lprt_aabb": abi.AABB, "lprt_light": abi.Light, "lprt_camera": abi.Camera, "lprt_skybox": abi.Skybox,
+        "lprt_frame_settings": abi.FrameSettings, "lprt_ray": abi.Ray, "lprt_hit": abi.Hit, "lprt_counters": abi.Counters,
+    }
+    lines = ["#include <stdio.h>", "#include <stddef.h>", f'#include "{HEADER}"', "int main(void){"]
+    for cname, cls in fields.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ['printf("LPRT_BUF_COUNT %d\\n", (int)LPRT_BUF_COUNT);', 'printf("LPRT_STAGE_COUNT %d\\n", (int)LPRT_STAGE_COUNT);',
+              "return 0;}"]
+    with tempfile.TemporaryDirectory() as d:
+        src, exe = os.path.join(d, "t.c"), os.path.join(d, "t")
+        open(src, "w").write("\n".join(lines))
+        subprocess.run(["gcc", "-std=c99", "-o", exe, src], check=True)
+        out = dict(l.split() for l in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in fields.items():
+        assert int(out[cname]) == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(out[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
+    assert int(out["LPRT_BUF_COUNT"]) == len(abi.BUF) and int(out["LPRT_STAGE_COUNT"]) == len(abi.STAGES)
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    declared = set(re.findall(r"\b(lprt_[a-z0-9_]+)\s*\(", open(HEADER).read()))
+    assert declared, "no declarations parsed"
+    lib = renderer.load_library()  # raises if any bound symbol is missing
+    bound = {name for name, _, _ in renderer.SYMBOLS}
+    assert declared == bound, (declared - bound, bound - declared)
+    for name in declared:
+        getattr(lib, name)
+    assert b"gfx950" in lib.lprt_version()
+
+
+def test_create_fails_loudly_without_a_gpu_or_with_bad_arguments():
+    lib = renderer.load_library()
+    h = C.c_void_p()
+    assert lib.lprt_create(C.byref(h), 0, 0, 64, 0, 64, 0) == -1  # LPRT_ERR_INVALID: zero width
+    assert lib.lprt_create(C.byref(h), 0, 64, 64, 10, 5, 0) == -1
+    import torch
+    if not torch.cuda.is_available():
+        assert lib.lprt_create(C.byref(h), 0, 64, 64, 0, 64, 0) == -3  # LPRT_ERR_NO_DEVICE: no CPU fallback
+        assert b"no CPU fallback" in lib.lprt_last_error(None)
+
+
+def test_strip_partition_covers_the_frame():
+    for H, N in [(1080, 1), (1080, 2), (1080, 4), (1080, 8), (2160, 8), (1081, 4), (7, 8)]:
+        rows = [dist.strip_rows(H, N, r) for r in range(N)]
+        assert rows[0][0] == 0 and rows[-1][1] == H
+        assert all(rows[i][1] == rows[i + 1][0] for i in range(N - 1))
+        for r in range(N):
+            wb, we = dist.window_rows(H, N, r)
+            assert 0 <= wb <= rows[r][0] and rows[r][1] <= we <= H
+            assert rows[r][0] - wb <= dist.HALO_ROWS and we - rows[r][1] <= dist.HALO_ROWS
+    assert dist.strip_rows(1080, 8, 3) == (405, 540) and dist.strip_rows(2160, 8, 7) == (1890, 2160)
