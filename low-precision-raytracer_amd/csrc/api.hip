@@ -96,7 +96,7 @@ template <typename T> struct Impl : CtxBase {
     bool have_scene = false;
 
     // RTRTProcedureBuffer + GBuffer + SVGFBuffer x2 + output surface, one arena
-    DevBuf arena, d_readback, d_last_L2W;
+    DevBuf arena, d_readback, d_last_L2W, d_rng_planes;
     FrameDev<T> fb{};
     V4<T> *taa_a = nullptr, *taa_b = nullptr;
     RngStore rng;
@@ -185,7 +185,6 @@ template <typename T> struct Impl : CtxBase {
         fb.prev_frame_count = carve<uint8_t>(off, n);
         fb.last_frame_id = carve<uint2>(off, n);
         fb.output = carve<float4>(off, n);
-        fb.rng_state = carve<uint32_t>(off, 5 * n);
         off = (off + 255) & ~size_t(255);
     }
     void ensure_frame_buffers() {
@@ -233,14 +232,33 @@ template <typename T> struct Impl : CtxBase {
         };
         stage(LPRT_STAGE_PRIMARY, [&] { launch_fill_gbuffer<T>(stream, sc, fb, stage_counters(LPRT_STAGE_PRIMARY)); });
         const bool first = frame_index == 0;
-        uint32_t d_a = 0;
+        // every curand_init of this frame in one batch: seed A of sample 0 (TAA jitter, frames >= 1) + seed B of each
+        // sample (shade #1 with GI).  shade #2 runs with NO_GI and draws nothing (cuda.hpp:1900-1999).
+        std::vector<uint64_t> seeds;
         if (!first)
-            stage(LPRT_STAGE_RNG, [&] { d_a = rng.generate(stream, seed_of(0, 0), total_px, first_px, npix, fb.rng_state); });
+            seeds.push_back(seed_of(0, 0));
+        if (fs.gi_on)
+            for (uint32_t s = 0; s < spp; s++)
+                seeds.push_back(seed_of(s, 1));
+        std::vector<uint32_t> seed_d(seeds.size() + 1, 0u);
+        if (!seeds.empty()) {
+            d_rng_planes.reserve(sizeof(uint32_t) * 5 * (size_t)npix * seeds.size());
+            stage(LPRT_STAGE_RNG, [&] {
+                rng.generate(stream, seeds.data(), (uint32_t)seeds.size(), total_px, first_px, npix, d_rng_planes.as<uint32_t>(), seed_d.data());
+            });
+        }
+        uint32_t next_plane = 0;
+        fb.rng_state = d_rng_planes.as<uint32_t>();
+        uint32_t d_a = first ? 0u : seed_d[next_plane];
         stage(LPRT_STAGE_TEMPORAL_MAP, [&] { launch_temporal_map<T>(stream, sc, fb, first, d_a); });
+        if (!first)
+            next_plane++;
         for (uint32_t s = 0; s < spp; s++) {
             uint32_t d_b = 0;
-            if (fs.gi_on)
-                stage(LPRT_STAGE_RNG, [&] { d_b = rng.generate(stream, seed_of(s, 1), total_px, first_px, npix, fb.rng_state); });
+            if (fs.gi_on) {
+                fb.rng_state = d_rng_planes.as<uint32_t>() + (size_t)next_plane * 5 * npix;
+                d_b = seed_d[next_plane++];
+            }
             stage(LPRT_STAGE_SHADE1, [&] { launch_shade<T>(stream, sc, fb, true, !fs.gi_on, d_b); });
             stage(LPRT_STAGE_TRACE_DI1, [&] { launch_trace_di<T>(stream, sc, fb, true, stage_counters(LPRT_STAGE_TRACE_DI1)); });
             if (fs.gi_on) {
@@ -457,7 +475,8 @@ template <typename T> struct Impl : CtxBase {
             throw std::string("rng_states: pixel range outside the frame");
         DevBuf planes;
         planes.reserve(sizeof(uint32_t) * 5 * (size_t)count);
-        uint32_t d = rng.generate(stream, seed, win.W * win.H, first, count, planes.as<uint32_t>());
+        uint32_t d = 0;
+        rng.generate(stream, &seed, 1, win.W * win.H, first, count, planes.as<uint32_t>(), &d);
         std::vector<uint32_t> host(5 * (size_t)count);
         LPRT_HIP(hipMemcpyAsync(host.data(), planes.ptr, sizeof(uint32_t) * host.size(), hipMemcpyDeviceToHost, stream));
         LPRT_HIP(hipStreamSynchronize(stream));

@@ -38,8 +38,9 @@ struct RngStore {
     bool ready = false;
     DevBuf d_mats, d_w3, d_w2, d_w1;
     void init(hipStream_t st);
-    // xorwow states of curand_init(seed, n, 0) for global pixels n in [first, first + count) -> planes[5][count]; returns d
-    uint32_t generate(hipStream_t st, uint64_t seed, uint32_t total_pixels, uint32_t first, uint32_t count, uint32_t *planes);
+    // xorwow states of curand_init(seed_i, n, 0) for global pixels n in [first, first + count) -> planes[i][5][count], d_out[i]
+    void generate(hipStream_t st, const uint64_t *seeds, uint32_t n_seeds, uint32_t total_pixels, uint32_t first, uint32_t count, uint32_t *planes,
+                  uint32_t *d_out);
 };
 
 } // namespace lprt

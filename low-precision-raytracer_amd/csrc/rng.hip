@@ -10,6 +10,7 @@
 // scalar loads while the 64 lanes hold 64 different source vectors: one matvec per pixel, ~1.8k VALU ops,
 // instead of ~16 dependent matvecs with per-lane matrices.
 #include "kernels.hpp"
+#include <algorithm>
 #include <mutex>
 #include <string>
 
@@ -21,38 +22,58 @@ struct XorMat {
 };
 
 // dst[(s*64 + j) - dst_first] = P[j] * src[s].  One block = 64 consecutive s x 16 consecutive j; a wave owns 4 j.
-struct TopVectors { // level-3 source vectors (host-computed, <= 64 of them), passed by value: no copy, no sync
+// level-3 source vectors (host-computed), passed by value: no copy, no sync.  Up to RNG_MAX_BATCH seeds per launch
+// (gridDim.z) x up to 16 vectors each (frames up to 4.19 Mpixel); larger frames go one seed per launch (64 vectors).
+constexpr int RNG_MAX_BATCH = 8;
+struct TopBatch {
+    uint32_t v[RNG_MAX_BATCH][5][16];
+};
+struct TopVectors {
     uint32_t v[5][64];
 };
-template <bool FROM_ARGS>
-__global__ void __launch_bounds__(256) k_rng_expand(const XorMat *__restrict__ P, const uint32_t *__restrict__ src, TopVectors top, uint32_t n_src,
-                                                    uint32_t src_stride, uint32_t *__restrict__ dst, uint32_t dst_first, uint32_t dst_count,
-                                                    uint32_t dst_stride) {
+
+// dst[(s*64 + j) - dst_first] = P[j] * src[s].  One block = 64 consecutive s x 16 consecutive j; a wave owns 4 j.
+// The wave's current matrix (5 KB) is staged in LDS with vector loads and its columns are then read back as
+// wave-uniform broadcasts: scalar loads of the columns (the obvious form) are limited by scalar-cache fills.
+// blockIdx.z = seed of a batch: src / dst planes of seed z start at z * src_seed_stride / z * dst_seed_stride.
+template <int TOP>
+__global__ void __launch_bounds__(256) k_rng_expand(const XorMat *__restrict__ P, const uint32_t *__restrict__ src, TopBatch topb, TopVectors top1,
+                                                    uint32_t n_src, uint32_t src_stride, uint32_t src_seed_stride, uint32_t *__restrict__ dst,
+                                                    uint32_t dst_first, uint32_t dst_count, uint32_t dst_stride, uint32_t dst_seed_stride) {
+    __shared__ uint4 mat[4][160 * 2]; // [wave][column][8 words]
     __shared__ uint32_t tile[5][64][17];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t s = blockIdx.x * 64 + lane;
     const uint32_t jbase = blockIdx.y * 16;
+    const uint32_t z = blockIdx.z;
+    src += (size_t)z * src_seed_stride;
+    dst += (size_t)z * dst_seed_stride;
     uint32_t v[5] = {0, 0, 0, 0, 0};
     if (s < n_src)
         for (int k = 0; k < 5; k++)
-            v[k] = FROM_ARGS ? top.v[k][s & 63] : src[k * src_stride + s];
+            v[k] = TOP == 2 ? topb.v[z][k][s & 15] : (TOP == 1 ? top1.v[k][s & 63] : src[k * src_stride + s]);
     for (uint32_t jj = 0; jj < 4; jj++) {
         const uint32_t jl = wave * 4 + jj; // 0..15 within the block
-        const uint32_t j = __builtin_amdgcn_readfirstlane(jbase + jl);
-        const XorMat *m = P + j;
+        const uint4 *m = reinterpret_cast<const uint4 *>(P + jbase + jl);
+        for (uint32_t q = lane; q < 320; q += 64)
+            mat[wave][q] = m[q];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
 #pragma unroll
         for (int w = 0; w < 5; w++) {
             const uint32_t bits = v[w];
 #pragma unroll 8
             for (int b = 0; b < 32; b++) {
-                const uint32_t *c = m->col[w * 32 + b];
+                const uint4 c03 = mat[wave][2 * (w * 32 + b)];
+                const uint32_t c4 = mat[wave][2 * (w * 32 + b) + 1].x;
                 const uint32_t mask = (uint32_t)__builtin_amdgcn_sbfe((int)bits, b, 1); // 0 or ~0
-                a0 ^= c[0] & mask;
-                a1 ^= c[1] & mask;
-                a2 ^= c[2] & mask;
-                a3 ^= c[3] & mask;
-                a4 ^= c[4] & mask;
+                a0 ^= c03.x & mask;
+                a1 ^= c03.y & mask;
+                a2 ^= c03.z & mask;
+                a3 ^= c03.w & mask;
+                a4 ^= c4 & mask;
             }
         }
         tile[0][lane][jl] = a0;
@@ -60,6 +81,7 @@ __global__ void __launch_bounds__(256) k_rng_expand(const XorMat *__restrict__ P
         tile[2][lane][jl] = a2;
         tile[3][lane][jl] = a3;
         tile[4][lane][jl] = a4;
+        __builtin_amdgcn_wave_barrier(); // the next staging overwrites mat[wave]: all lanes must be done reading
     }
     __syncthreads();
     // coalesced write-out: for each of the 64 sources, 16 consecutive destinations
@@ -159,37 +181,63 @@ void RngStore::init(hipStream_t st) {
     ready = true;
 }
 
-// fills `planes` ([5][count], plane stride = count) with the states of pixels [first, first+count); returns d(seed)
-uint32_t RngStore::generate(hipStream_t st, uint64_t seed, uint32_t total_pixels, uint32_t first, uint32_t count, uint32_t *planes) {
-    // curand_init seed scramble
+static inline void seed_state(uint64_t seed, uint32_t v[5], uint32_t &d) { // curand_init seed scramble
     uint32_t s0 = (uint32_t)seed ^ 0xaad26b49u, s1 = (uint32_t)(seed >> 32) ^ 0xf7dcefddu;
     uint32_t t0 = 1099087573u * s0, t1 = 2591861531u * s1;
-    uint32_t d = 6615241u + t1 + t0;
-    uint32_t v[5] = {123456789u + t0, 362436069u ^ t0, 521288629u + t1, 88675123u ^ t1, 5783321u + t0};
+    d = 6615241u + t1 + t0;
+    v[0] = 123456789u + t0;
+    v[1] = 362436069u ^ t0;
+    v[2] = 521288629u + t1;
+    v[3] = 88675123u ^ t1;
+    v[4] = 5783321u + t0;
+}
+
+// fills planes[i] ([5][count] each, seed stride 5*count) with the states of pixels [first, first+count) for every
+// seed of the batch; d_out[i] = d(seed i).  No host synchronisation.
+void RngStore::generate(hipStream_t st, const uint64_t *seeds, uint32_t n_seeds, uint32_t total_pixels, uint32_t first, uint32_t count,
+                        uint32_t *planes, uint32_t *d_out) {
     const Tables &t = tables();
     const uint32_t n1 = (total_pixels + 63) / 64, n2 = (n1 + 63) / 64, n3 = (n2 + 63) / 64;
-    // level-3 vectors on the host, handed to the first expansion as kernel arguments
     if (n3 > 64)
         throw std::string("frame too large for the RNG expansion (more than 2^24 pixels)");
-    TopVectors top{};
-    for (uint32_t j = 0; j < n3; j++) {
-        for (int k = 0; k < 5; k++)
-            top.v[k][j] = v[k];
-        h_apply(t.m_top, v, v);
-    }
-    d_w2.reserve(sizeof(uint32_t) * 5 * (size_t)n3 * 64);
-    d_w1.reserve(sizeof(uint32_t) * 5 * (size_t)n2 * 64);
     const XorMat *mats = d_mats.as<XorMat>();
-    hipLaunchKernelGGL(k_rng_expand<true>, dim3((n3 + 63) / 64, 4), dim3(256), 0, st, mats + 128, (const uint32_t *)nullptr, top, n3, n3,
-                       d_w2.as<uint32_t>(), 0u, n3 * 64, n3 * 64);
-    hipLaunchKernelGGL(k_rng_expand<false>, dim3((n2 + 63) / 64, 4), dim3(256), 0, st, mats + 64, d_w2.as<uint32_t>(), top, n2, n3 * 64,
-                       d_w1.as<uint32_t>(), 0u, n2 * 64, n2 * 64);
-    // last level only for the L1 vectors that cover [first, first + count)
+    const uint32_t w2_stride = n3 * 64, w1_stride = n2 * 64;
     const uint32_t s_begin = first / 64, s_end = (first + count + 63) / 64;
-    hipLaunchKernelGGL(k_rng_expand<false>, dim3((s_end - s_begin + 63) / 64, 4), dim3(256), 0, st, mats, d_w1.as<uint32_t>() + s_begin, top,
-                       s_end - s_begin, n2 * 64, planes, first - s_begin * 64, count, count);
+    uint32_t done = 0;
+    while (done < n_seeds) {
+        const uint32_t batch = n3 <= 16 ? std::min<uint32_t>(RNG_MAX_BATCH, n_seeds - done) : 1;
+        d_w2.reserve(sizeof(uint32_t) * 5 * (size_t)w2_stride * batch);
+        d_w1.reserve(sizeof(uint32_t) * 5 * (size_t)w1_stride * batch);
+        TopBatch topb{};
+        TopVectors top1{};
+        for (uint32_t b = 0; b < batch; b++) {
+            uint32_t v[5];
+            seed_state(seeds[done + b], v, d_out[done + b]);
+            for (uint32_t j = 0; j < n3; j++) {
+                for (int k = 0; k < 5; k++) {
+                    if (n3 <= 16)
+                        topb.v[b][k][j] = v[k];
+                    else
+                        top1.v[k][j] = v[k];
+                }
+                h_apply(t.m_top, v, v);
+            }
+        }
+        uint32_t *out = planes + (size_t)done * 5 * count;
+        if (n3 <= 16)
+            hipLaunchKernelGGL(k_rng_expand<2>, dim3((n3 + 63) / 64, 4, batch), dim3(256), 0, st, mats + 128, (const uint32_t *)nullptr, topb, top1, n3,
+                               0u, 0u, d_w2.as<uint32_t>(), 0u, w2_stride, w2_stride, 5 * w2_stride);
+        else
+            hipLaunchKernelGGL(k_rng_expand<1>, dim3((n3 + 63) / 64, 4, batch), dim3(256), 0, st, mats + 128, (const uint32_t *)nullptr, topb, top1, n3,
+                               0u, 0u, d_w2.as<uint32_t>(), 0u, w2_stride, w2_stride, 5 * w2_stride);
+        hipLaunchKernelGGL(k_rng_expand<0>, dim3((n2 + 63) / 64, 4, batch), dim3(256), 0, st, mats + 64, d_w2.as<uint32_t>(), topb, top1, n2, w2_stride,
+                           5 * w2_stride, d_w1.as<uint32_t>(), 0u, w1_stride, w1_stride, 5 * w1_stride);
+        // last level only for the L1 vectors that cover [first, first + count)
+        hipLaunchKernelGGL(k_rng_expand<0>, dim3((s_end - s_begin + 63) / 64, 4, batch), dim3(256), 0, st, mats, d_w1.as<uint32_t>() + s_begin, topb,
+                           top1, s_end - s_begin, w1_stride, 5 * w1_stride, out, first - s_begin * 64, count, count, 5 * count);
+        done += batch;
+    }
     LPRT_HIP(hipGetLastError());
-    return d;
 }
 
 } // namespace lprt

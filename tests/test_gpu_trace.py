@@ -102,7 +102,7 @@ def test_skip_geometry_and_distance_window(cornell):
     o = Oracle(16, 16, abi.F32)
     o.load_scene(cornell)
     rays = np.zeros(4, dtype=abi.RAY_DTYPE)
-    rays["source"] = (0.0, 0.0, 3.5)
+    rays["source"] = (0.31, 0.17, 3.5)  # off the wall's diagonal: the shared edge itself is a strict-test miss (Q14)
     rays["direction"] = (0.0, 0.0, -1.0)
     rays["max_distance"] = [1e5, 1e5, 4.0, 1e5]
     rays["min_distance"] = [0.0, 0.0, 0.0, 4.6]
