@@ -88,7 +88,8 @@ struct CtxBase {
 template <typename T> struct Impl : CtxBase {
     GeometryStore<T> geo;
     TlasStore<T> tlas;
-    DevBuf d_materials32, d_materials, d_objects32, d_objects, d_lights32, d_lights, d_counters, d_rays, d_hits;
+    DevBuf d_materials32, d_materials, d_objects32, d_objects, d_lights32, d_lights, d_counters, d_rays, d_hits, d_objrecs;
+    bool objrecs_dirty = true;
     uint32_t n_materials = 0, n_objects = 0, n_lights = 0;
     lprt_camera camera{};
     lprt_skybox skybox{};
@@ -216,8 +217,11 @@ template <typename T> struct Impl : CtxBase {
         ensure_frame_buffers();
         ensure_last_L2W();
         const uint32_t spp = fs.spp ? fs.spp : 1;
-        if (fs.rebuild_blas)
+        if (fs.rebuild_blas) {
             stage(LPRT_STAGE_BUILD_BLAS, [&] { geo.build_blas(stream); });
+            objrecs_dirty = true;
+            ensure_objrecs();
+        }
         SceneDev<T> sc = scene_dev();
         // camera + reprojection matrices in DataT (RDCamera<DataT>, transform_W2C)
         for (int k = 0; k < 16; k++)
@@ -364,6 +368,15 @@ template <typename T> struct Impl : CtxBase {
     }
     void build_blas() override {
         stage(LPRT_STAGE_BUILD_BLAS, [&] { geo.build_blas(stream); });
+        objrecs_dirty = true;
+    }
+    void ensure_objrecs() {
+        if (!objrecs_dirty)
+            return;
+        d_objrecs.reserve(sizeof(ObjRec<T>) * (size_t)std::max(n_objects, 1u));
+        launch_make_objrecs<T>(stream, tlas.d_slots.template as<ObjSlot<T>>(), d_objects.template as<ObjConst<T>>(), geo.d_blas.template as<BlasInfo>(),
+                               geo.d_roots.template as<T>(), n_objects, geo.n_vaos, d_objrecs.as<ObjRec<T>>());
+        objrecs_dirty = false;
     }
     void set_scene(const lprt_object *obj, const lprt_aabb *aabbs, uint32_t n, const lprt_light *lights, uint32_t nl,
                    const lprt_camera *cam, const float *W2C, const lprt_skybox *sky) override {
@@ -388,6 +401,7 @@ template <typename T> struct Impl : CtxBase {
         else
             skybox = lprt_skybox{};
         have_scene = true;
+        objrecs_dirty = true;
     }
     SceneDev<T> scene_dev() const {
         SceneDev<T> sc{};
@@ -395,6 +409,7 @@ template <typename T> struct Impl : CtxBase {
         sc.tlas_leaf = tlas.d_leaf.template as<uint32_t>();
         sc.tlas_root = tlas.d_root.template as<T>();
         sc.tlas_slots = tlas.d_slots.template as<ObjSlot<T>>();
+        sc.objrecs = d_objrecs.template as<ObjRec<T>>();
         sc.tlas_depth = tlas.depth;
         sc.n_objects = tlas.n_objects;
         sc.objects = d_objects.template as<ObjConst<T>>();
@@ -427,6 +442,7 @@ template <typename T> struct Impl : CtxBase {
             throw std::string("BLAS not built: call lprt_build_blas after lprt_upload_geometry");
         if (!have_scene)
             throw std::string("no scene: call lprt_set_scene first");
+        ensure_objrecs();
     }
     void trace_rays(const lprt_ray *rays, uint32_t n, int find_any, lprt_hit *hits) override {
         require_ready();

@@ -7,6 +7,9 @@ namespace lprt {
 // trace_kernels.hip
 template <typename T>
 void launch_trace_rays(hipStream_t st, const SceneDev<T> &sc, const lprt_ray *rays, uint32_t n, bool any, lprt_hit *hits, Counters *counters);
+template <typename T>
+void launch_make_objrecs(hipStream_t st, const ObjSlot<T> *slots, const ObjConst<T> *objects, const BlasInfo *blas, const T *roots, uint32_t n,
+                         uint32_t n_vaos, ObjRec<T> *out);
 template <typename T> void launch_convert_objects(hipStream_t st, const lprt_object *in, ObjConst<T> *out, uint32_t n);
 template <typename T> void launch_convert_materials(hipStream_t st, const lprt_material *in, MaterialT<T> *out, uint32_t n);
 template <typename T> void launch_convert_lights(hipStream_t st, const lprt_light *in, LightT<T> *out, uint32_t n);

@@ -18,6 +18,33 @@ template <typename T> struct SvgfConst {
     static LPRT_DEV T eps() { return cvt<T>(1e-5f); } // a half subnormal (cuda.hpp:1261)
 };
 
+// Edge-stopping weights are exp() / pow(x,128) of per-tap quantities: 4 transcendentals per tap made the filters
+// ALU-bound (390 us per a-trous level at 1080p).  The default build evaluates them with the hardware exp2 and 7
+// squarings (relative error <= ~4e-6 in f32, invisible after rounding to half); -DLPRT_EXACT_SVGF_MATH restores the
+// libm-accurate forms the parity of the other stages is measured with.
+LPRT_DEV float svgf_exp(float x) {
+#ifdef LPRT_EXACT_SVGF_MATH
+    return ::expf(x);
+#else
+    return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f);
+#endif
+}
+LPRT_DEV float svgf_div(float a, float b) { // a / b: IEEE in the exact build, a * rcp(b) (1 ulp) otherwise
+#ifdef LPRT_EXACT_SVGF_MATH
+    return a / b;
+#else
+    return a * __builtin_amdgcn_rcpf(b);
+#endif
+}
+LPRT_DEV float svgf_pow128(float x) {
+#ifdef LPRT_EXACT_SVGF_MATH
+    return ::powf(x, 128.f);
+#else
+    float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8, x32 = x16 * x16, x64 = x32 * x32;
+    return x64 * x64;
+#endif
+}
+
 // sample_linear (cuda.hpp:1085-1115) on a 4-vector plane: xyz blended, result / sum via the rounded reciprocal
 template <typename T> LPRT_DEV V3<T> sample_linear3(const TemporalMapT<T> &m, const V4<T> *arr, uint32_t W, V3<T> dflt) {
     if (m.frame_count == 0)
@@ -63,29 +90,45 @@ template <typename T> __global__ void __launch_bounds__(256) k_depth_gradient(Fr
 // ---- temporal_accumulation_color (cuda.hpp:1187-1243), both lobes -------------------------------------------------
 // Reads the lobe's cv_a (this frame) and cv_b (history), writes cv_c.rgb and illum: out of place, so the 9x9
 // window always sees this frame's unmodified input (the reference updates in place and races).
+// One workgroup = a 32x8 pixel tile; the (32+8)x(8+8) input window of both lobes is staged in LDS once (5 loads per
+// thread instead of 162) and the 81 taps are LDS reads, accumulated in the reference's order (x outer, y inner).
+constexpr int TC_BX = 32, TC_BY = 8, TC_R = 4, TC_TW = TC_BX + 2 * TC_R, TC_TH = TC_BY + 2 * TC_R;
 template <typename T>
 __global__ void __launch_bounds__(256) k_temporal_color(FrameDev<T> fb, T color_w) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= fb.win.npix())
-        return;
+    __shared__ V4<T> tile[2][TC_TH][TC_TW];
     const int W = (int)fb.win.W, R = (int)fb.win.rows();
-    const int px = (int)(p % fb.win.W), py = (int)(p / fb.win.W);
+    const int tx = (int)(threadIdx.x % TC_BX), ty = (int)(threadIdx.x / TC_BX);
+    const int x0 = (int)blockIdx.x * TC_BX - TC_R, y0 = (int)blockIdx.y * TC_BY - TC_R;
+    for (int e = (int)threadIdx.x; e < TC_TW * TC_TH; e += 256) {
+        const int lx = e % TC_TW, ly = e / TC_TW;
+        const int gx = x0 + lx, gy = y0 + ly;
+        if (gx >= 0 && gx < W && gy >= 0 && gy < R) {
+            const uint32_t q = (uint32_t)(gy * W + gx);
+            tile[0][ly][lx] = fb.lobe[0].cv_a[q];
+            tile[1][ly][lx] = fb.lobe[1].cv_a[q];
+        }
+    }
+    __syncthreads();
+    const int px = (int)blockIdx.x * TC_BX + tx, py = (int)blockIdx.y * TC_BY + ty;
+    if (px >= W || py >= R)
+        return;
+    const uint32_t p = (uint32_t)(py * W + px);
     const TemporalMapT<T> ti = fb.svgf_map[p];
     const T zero = (T)0, one = (T)1, half_ = cvt<T>(0.5f);
 #pragma unroll
     for (int l = 0; l < 2; l++) {
-        const V4<T> *in = fb.lobe[l].cv_a;
-        V3<T> pc = xyz(in[p]);
+        V3<T> pc = xyz(tile[l][ty + TC_R][tx + TC_R]);
         V3<T> m1 = zero3<T>(), m2 = zero3<T>(), wt = zero3<T>();
         for (int i = -4; i <= 4; i++) {
             int qx = px + i;
             if (qx < 0 || qx >= W)
                 continue;
+#pragma unroll
             for (int j = -4; j <= 4; j++) {
                 int qy = py + j;
                 if (qy < 0 || qy >= R)
                     continue;
-                V4<T> q = in[qy * W + qx];
+                V4<T> q = tile[l][ty + TC_R + j][tx + TC_R + i];
                 if (tfinite(q.x)) { wt.x = wt.x + one; m1.x = m1.x + q.x; m2.x = m2.x + q.x * q.x; }
                 if (tfinite(q.y)) { wt.y = wt.y + one; m1.y = m1.y + q.y; m2.y = m2.y + q.y * q.y; }
                 if (tfinite(q.z)) { wt.z = wt.z + one; m1.z = m1.z + q.z; m2.z = m2.z + q.z * q.z; }
@@ -114,8 +157,8 @@ template <typename T> LPRT_DEV void geo_weights(T depth_p, T depth_q, V2<T> grad
     // exp(-abs(dz) / (SIGMA_Z * abs(dot(grad, dp) + EPS))): the unary minus makes the quotient a float
     float num = -(float)tabs(depth_p - depth_q);
     float den = (float)((T)1 * tabs(dot(grad, V2<T>{dx, dy}) + SvgfConst<T>::eps()));
-    w_z = cvt<T>(::expf(num / den));
-    w_n = tpow(tmax((T)0, dot(n_p, n_q)), cvt<T>(128.f));
+    w_z = cvt<T>(svgf_exp(svgf_div(num, den)));
+    w_n = cvt<T>(svgf_pow128((float)tmax((T)0, dot(n_p, n_q))));
 }
 
 // ---- temporal_accumulation_moments (cuda.hpp:1245-1337), both lobes ---------------------------------------------------
@@ -188,19 +231,44 @@ __global__ void __launch_bounds__(256) k_moments(FrameDev<T> fb, T moments_w) {
 }
 
 // ---- wavelet_filter<stride> (cuda.hpp:1339-1440), both lobes ---------------------------------------------------------------
+// One workgroup filters 64 x 4 points of ONE phase of the stride-s lattice (rows oy + s*k): on that lattice the a-trous
+// filter is a dense 5-row stencil, so the 8 lattice rows x (64 + 4s) columns it needs are staged in LDS once (every
+// load a full coalesced row segment) and the 25 taps x 4 planes become LDS reads — for every stride, including 8 and
+// 16 where a plain image tile would not fit.  Per thread: ~10-16 global loads instead of 125.
+constexpr int WV_BX = 64, WV_BY = 4;
 template <typename T, int STRIDE>
 __global__ void __launch_bounds__(256) k_wavelet(FrameDev<T> fb, const V4<T> *in0, V4<T> *out0, const V4<T> *in1, V4<T> *out1) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= fb.win.npix())
-        return;
+    constexpr int TW = WV_BX + 4 * STRIDE, TH = WV_BY + 4;
+    __shared__ V4<T> s_nd[TH][TW], s_c0[TH][TW], s_c1[TH][TW];
+    __shared__ V2<T> s_il[TH][TW];
     const int W = (int)fb.win.W, R = (int)fb.win.rows();
-    const int px = (int)(p % fb.win.W), py = (int)(p / fb.win.W);
+    const int tx = (int)(threadIdx.x % WV_BX), ty = (int)(threadIdx.x / WV_BX);
+    const int oy = (int)(blockIdx.y % STRIDE), by = (int)(blockIdx.y / STRIDE);
+    const int x0 = (int)blockIdx.x * WV_BX - 2 * STRIDE; // image x of tile column 0
+    const int r0 = WV_BY * by - 2;                        // lattice row of tile row 0
+    for (int e = (int)threadIdx.x; e < TW * TH; e += 256) {
+        const int lx = e % TW, ly = e / TW;
+        const int gx = x0 + lx, gy = oy + STRIDE * (r0 + ly);
+        if (gx >= 0 && gx < W && gy >= 0 && gy < R) {
+            const uint32_t q = (uint32_t)(gy * W + gx);
+            s_nd[ly][lx] = fb.g_normal_depth[q];
+            s_c0[ly][lx] = in0[q];
+            s_c1[ly][lx] = in1[q];
+            s_il[ly][lx] = V2<T>{fb.lobe[0].illum[q], fb.lobe[1].illum[q]};
+        }
+    }
+    __syncthreads();
+    const int px = (int)blockIdx.x * WV_BX + tx, py = oy + STRIDE * (WV_BY * by + ty);
+    if (px >= W || py >= R)
+        return;
+    const uint32_t p = (uint32_t)(py * W + px);
+    const int cx = tx + 2 * STRIDE, cy = ty + 2; // tile coordinates of the centre
     const T zero = (T)0;
     const T hk[3] = {cvt<T>(0.375f), cvt<T>(0.25f), cvt<T>(0.0625f)};
     const T gk[2] = {cvt<T>(0.5f), cvt<T>(0.25f)};
     const V4<T> *in[2] = {in0, in1};
     V4<T> *out[2] = {out0, out1};
-    // 1. 3x3 gaussian of the variance -> sigma_l
+    // 1. 3x3 gaussian of the variance (image neighbours, not lattice neighbours) -> sigma_l
     T sg[2] = {zero, zero};
     T gw = zero;
     for (int i = -1; i <= 1; i++) {
@@ -220,35 +288,40 @@ __global__ void __launch_bounds__(256) k_wavelet(FrameDev<T> fb, const V4<T> *in
     }
     sg[0] = tsqrt(tdiv(sg[0], gw));
     sg[1] = tsqrt(tdiv(sg[1], gw));
-    // 2. 5x5 a-trous taps
-    const V4<T> nd_p = fb.g_normal_depth[p];
+    // w_l = exp(-|l_p - l_q| / (4 sigma_l + eps)): the denominator is per pixel
+    const float den_l[2] = {(float)(cvt<T>(4.f) * sg[0] + SvgfConst<T>::eps()), (float)(cvt<T>(4.f) * sg[1] + SvgfConst<T>::eps())};
+    // 2. 5x5 a-trous taps, x outer / y inner as in the reference
+    const V4<T> nd_p = s_nd[cy][cx];
     const V2<T> grad = fb.depth_gradient[p];
-    const T illum_p[2] = {fb.lobe[0].illum[p], fb.lobe[1].illum[p]};
+    const V2<T> il_p = s_il[cy][cx];
+    const T illum_p[2] = {il_p.x, il_p.y};
     T nvar[2] = {zero, zero}, wv[2] = {zero, zero}, wc[2] = {zero, zero};
     V3<T> ncol[2] = {zero3<T>(), zero3<T>()};
+#pragma unroll
     for (int i = -2; i <= 2; i++) {
         int qx = px + STRIDE * i;
         if (qx < 0 || qx >= W)
             continue;
+#pragma unroll
         for (int j = -2; j <= 2; j++) {
             int qy = py + STRIDE * j;
             if (qy < 0 || qy >= R)
                 continue;
-            uint32_t q = (uint32_t)(qy * W + qx);
+            const int lx = cx + STRIDE * i, ly = cy + j;
             T h = hk[i < 0 ? -i : i] * hk[j < 0 ? -j : j];
-            const V4<T> nd_q = fb.g_normal_depth[q];
+            const V4<T> nd_q = s_nd[ly][lx];
             T w_z, w_n;
             geo_weights(nd_p.w, nd_q.w, grad, cvt<T>((float)(STRIDE * i)), cvt<T>((float)(STRIDE * j)), xyz(nd_p), xyz(nd_q), w_z, w_n);
             T wzn = w_z * w_n;
+            const V2<T> il_q = s_il[ly][lx];
+            const T iq[2] = {il_q.x, il_q.y};
 #pragma unroll
             for (int l = 0; l < 2; l++) {
-                T iq = fb.lobe[l].illum[q];
-                float num = -(float)tabs(illum_p[l] - iq);
-                float den = (float)(cvt<T>(4.f) * sg[l] + SvgfConst<T>::eps());
-                T w_l = cvt<T>(::expf(num / den));
+                float num = -(float)tabs(illum_p[l] - iq[l]);
+                T w_l = cvt<T>(svgf_exp(svgf_div(num, den_l[l])));
                 T hw = h * (wzn * w_l);
                 if (tfinite(hw)) {
-                    V4<T> cq = in[l][q];
+                    const V4<T> cq = l == 0 ? s_c0[ly][lx] : s_c1[ly][lx];
                     if (tfinite(cq.w)) {
                         nvar[l] = nvar[l] + hw * hw * cq.w;
                         wv[l] = wv[l] + hw;
@@ -265,7 +338,7 @@ __global__ void __launch_bounds__(256) k_wavelet(FrameDev<T> fb, const V4<T> *in
     for (int l = 0; l < 2; l++) {
         T nv = tdiv(nvar[l], wv[l] * wv[l]);
         V3<T> nc = vdiv(ncol[l], wc[l]);
-        V4<T> centre = in[l][p];
+        V4<T> centre = l == 0 ? s_c0[cy][cx] : s_c1[cy][cx];
         value_or(nc, xyz(centre));
         if (!tfinite(nv))
             nv = centre.w;
@@ -352,7 +425,8 @@ template <typename T> void launch_depth_gradient(hipStream_t st, const FrameDev<
     hipLaunchKernelGGL(k_depth_gradient<T>, grid_for(fb.win.npix()), dim3(256), 0, st, fb);
 }
 template <typename T> void launch_temporal_color(hipStream_t st, const FrameDev<T> &fb, float color_w) {
-    hipLaunchKernelGGL(k_temporal_color<T>, grid_for(fb.win.npix()), dim3(256), 0, st, fb, (T)color_w);
+    dim3 grid((fb.win.W + TC_BX - 1) / TC_BX, (fb.win.rows() + TC_BY - 1) / TC_BY);
+    hipLaunchKernelGGL(k_temporal_color<T>, grid, dim3(256), 0, st, fb, (T)color_w);
 }
 template <typename T> void launch_moments(hipStream_t st, const FrameDev<T> &fb, float moments_w) {
     hipLaunchKernelGGL(k_moments<T>, grid_for(fb.win.npix()), dim3(256), 0, st, fb, (T)moments_w);
@@ -360,7 +434,9 @@ template <typename T> void launch_moments(hipStream_t st, const FrameDev<T> &fb,
 // level = 0..4 -> stride 1,2,4,8,16.  Buffer rotation (cuda.hpp:1678-1710 with cv_c in the role of color_inout, which
 // holds the integrated colour): L1 c->b (b = next frame's history), L2 b->a, L3 a->c, L4 c->a, L5 a->c; result in cv_c.
 template <typename T> void launch_wavelet(hipStream_t st, const FrameDev<T> &fb, int level) {
-    const dim3 g = grid_for(fb.win.npix()), b(256);
+    const uint32_t stride = 1u << level;
+    const uint32_t lattice_rows = (fb.win.rows() + stride - 1) / stride; // per phase (upper bound)
+    const dim3 g((fb.win.W + WV_BX - 1) / WV_BX, stride * ((lattice_rows + WV_BY - 1) / WV_BY)), b(256);
     const SvgfLobe<T> &a = fb.lobe[0], &w = fb.lobe[1];
     switch (level) {
     case 0: hipLaunchKernelGGL((k_wavelet<T, 1>), g, b, 0, st, fb, a.cv_c, a.cv_b, w.cv_c, w.cv_b); break;

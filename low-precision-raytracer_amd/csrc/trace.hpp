@@ -37,40 +37,29 @@ template <typename T> LPRT_DEV T slab_t(T bound, T origin, float inv) {
     return cvt<T>((float)(bound - origin) * inv);
 }
 
-// ray_aabb_intersection_scene / _object (cuda.hpp:70-149). Axes whose entry/exit is not finite are
-// ignored (parallel rays), as in the reference.
+// ray_aabb_intersection_scene / _object (cuda.hpp:70-149). Axes whose entry/exit is not finite are ignored
+// (parallel rays), as in the reference; entry = max over the remaining axes, exit = min (the reference's sequential
+// update computes exactly these extrema).
 template <typename T, bool SCENE> LPRT_DEV bool slab_test(const T *lo, const T *hi, const RaySlab<T> &rs, T &tmn, T &tmx) {
-    T a0 = slab_t(lo[0], rs.o.x, rs.ix), b0 = slab_t(hi[0], rs.o.x, rs.ix);
-    T a1 = slab_t(lo[1], rs.o.y, rs.iy), b1 = slab_t(hi[1], rs.o.y, rs.iy);
-    T a2 = slab_t(lo[2], rs.o.z, rs.iz), b2 = slab_t(hi[2], rs.o.z, rs.iz);
-    if (b0 < a0) { T s = a0; a0 = b0; b0 = s; }
-    if (b1 < a1) { T s = a1; a1 = b1; b1 = s; }
-    if (b2 < a2) { T s = a2; a2 = b2; b2 = s; }
-    bool upd = false;
-    T t1max = (T)0, t2min = (T)0;
-    if (tfinite(a0) && tfinite(b0)) { t1max = a0; t2min = b0; upd = true; }
-    if (tfinite(a1) && tfinite(b1)) {
-        if (!upd || t1max < a1) t1max = a1;
-        if (!upd || b1 < t2min) t2min = b1;
-        upd = true;
-    }
-    if (tfinite(a2) && tfinite(b2)) {
-        if (!upd || t1max < a2) t1max = a2;
-        if (!upd || b2 < t2min) t2min = b2;
-        upd = true;
-    }
-    if (!upd)
-        return false;
-    bool out;
-    if (SCENE) {
-        T s = t2min + cvt<T>(0.02f);
-        out = t1max <= s && 0.0f <= (float)s;
-    } else {
-        out = t1max <= t2min * cvt<T>(1.001953f) && 0.0f <= (float)t2min;
-    }
+    const T a0 = slab_t(lo[0], rs.o.x, rs.ix), b0 = slab_t(hi[0], rs.o.x, rs.ix);
+    const T a1 = slab_t(lo[1], rs.o.y, rs.iy), b1 = slab_t(hi[1], rs.o.y, rs.iy);
+    const T a2 = slab_t(lo[2], rs.o.z, rs.iz), b2 = slab_t(hi[2], rs.o.z, rs.iz);
+    const bool ok0 = tfinite(a0) && tfinite(b0), ok1 = tfinite(a1) && tfinite(b1), ok2 = tfinite(a2) && tfinite(b2);
+    const T ninf = tneg(Num<T>::inf()), pinf = Num<T>::inf();
+    const T n0 = ok0 ? tmin(a0, b0) : ninf, f0 = ok0 ? tmax(a0, b0) : pinf;
+    const T n1 = ok1 ? tmin(a1, b1) : ninf, f1 = ok1 ? tmax(a1, b1) : pinf;
+    const T n2 = ok2 ? tmin(a2, b2) : ninf, f2 = ok2 ? tmax(a2, b2) : pinf;
+    const T t1max = tmax(tmax(n0, n1), n2);
+    const T t2min = tmin(tmin(f0, f1), f2);
     tmn = t1max;
     tmx = t2min;
-    return out;
+    if (!(ok0 | ok1 | ok2))
+        return false;
+    if (SCENE) {
+        T s = t2min + cvt<T>(0.02f);
+        return t1max <= s && 0.0f <= (float)s;
+    }
+    return t1max <= t2min * cvt<T>(1.001953f) && 0.0f <= (float)t2min;
 }
 
 template <bool COUNT> struct Cnt {
@@ -181,32 +170,41 @@ LPRT_DEV bool tri_test(const SceneDev<T> &sc, uint32_t rec, const RayT<T> &ray, 
     return false;
 }
 
+// sorted range [l, r) of leaf k in the perfect tree of depth D over n primitives (csrc/build.hip::leaf_range): computed,
+// not loaded — one dependent fetch less per leaf
+LPRT_DEV void leaf_range_dev(uint32_t k, uint32_t D, uint32_t n, uint32_t &l, uint32_t &r) {
+    l = 0;
+    r = n;
+    for (int b = (int)D - 1; b >= 0; b--) {
+        uint32_t mid = l + ((r - l) >> 1);
+        if ((k >> b) & 1u)
+            l = mid;
+        else
+            r = mid;
+    }
+}
+
 // ---- T4: BLAS traversal (replaces search_intersection_in_object, cuda.hpp:415-504) -----------------
 template <typename T, bool ANY, bool COUNT>
-LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, uint32_t inscene_objid, uint32_t vao_index,
-                            uint32_t skip_vao, uint32_t skip_off, Isect<T> &is, T min_distance, T max_distance,
-                            Cnt<COUNT> &cnt) {
-    LPRT_CHECK(sc, vao_index < sc.n_vaos, 202, vao_index, sc.n_vaos);
-    const BlasInfo bi = sc.blas[vao_index];
+LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, const ObjRec<T> &ob, uint32_t skip_vao, uint32_t skip_off, Isect<T> &is,
+                            T min_distance, T max_distance, Cnt<COUNT> &cnt) {
     if (COUNT)
         cnt.objects++;
-    if (bi.n_tris == 0)
+    if (ob.n_tris == 0)
         return;
     const RaySlab<T> rs = make_slab(ray);
     T tmn, tmx;
     if (COUNT)
         cnt.blas_nodes++;
-    const T *rb = sc.blas_roots + 6 * bi.root_base;
-    if (!(slab_test<T, false>(rb, rb + 3, rs, tmn, tmx) && tmn < is.t && tmn < max_distance && tmx > min_distance))
+    if (!(slab_test<T, false>(ob.root_lo, ob.root_hi, rs, tmn, tmx) && tmn < is.t && tmn < max_distance && tmx > min_distance))
         return;
-    const InnerNode<T> *inner = sc.blas_inner + bi.inner_base;
-    const uint32_t *leaves = sc.blas_leaf + bi.leaf_base;
-    const uint32_t D = bi.depth;
-    const bool skip_here = (vao_index == skip_vao);
+    const InnerNode<T> *inner = sc.blas_inner + ob.inner_base;
+    const uint32_t D = ob.depth;
+    const bool skip_here = (ob.vao_index == skip_vao);
     uint32_t i = 1, c = 0, pending = 0;
     for (;;) {
         if (c < D) {
-            LPRT_CHECK(sc, bi.inner_base + i - 1 < sc.lim_inner, 203, bi.inner_base + i - 1, sc.lim_inner);
+            LPRT_CHECK(sc, ob.inner_base + i - 1 < sc.lim_inner, 203, ob.inner_base + i - 1, sc.lim_inner);
             const InnerNode<T> nd = inner[i - 1];
             if (COUNT)
                 cnt.blas_nodes += 2;
@@ -222,14 +220,13 @@ LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, uint32_t 
                 continue;
             }
         } else {
-            LPRT_CHECK(sc, bi.leaf_base + i - (1u << D) < sc.lim_leaves, 204, bi.leaf_base + i - (1u << D), sc.lim_leaves);
-            uint32_t lw = leaves[i - (1u << D)];
-            uint32_t first = bi.tri_base + (lw >> 1), count = (lw & 1u) + 1u;
-            for (uint32_t k = 0; k < count; k++) {
-                uint32_t rec = first + k;
+            uint32_t l, r;
+            leaf_range_dev(i - (1u << D), D, ob.n_tris, l, r);
+            for (uint32_t k = l; k < r; k++) {
+                uint32_t rec = ob.tri_base + k;
                 if (skip_here && sc.tris[rec].inobject_offset == skip_off) // cuda.hpp:446
                     continue;
-                tri_test<T, COUNT>(sc, rec, ray, inscene_objid, is, min_distance, max_distance, cnt);
+                tri_test<T, COUNT>(sc, rec, ray, ob.inscene_objid, is, min_distance, max_distance, cnt);
                 if (ANY && is.hit)
                     return;
             }
@@ -259,6 +256,29 @@ LPRT_DEV Isect<T> cast_ray(const SceneDev<T> &sc, const RayT<T> &ray, uint32_t s
         return is;
     const RaySlab<T> rs = make_slab(ray);
     T tmn, tmx;
+    if (sc.n_objects <= 32u) {
+        // Small scenes (the Cornell box has 8 instances): a tree over a handful of mutually overlapping boxes costs ~2n
+        // slab tests per ray; scan the n world boxes instead.  The loop is wave-uniform, so the boxes arrive through
+        // scalar loads, and the object phase below starts with every lane's candidate list complete.
+        uint32_t cand = 0;
+        for (uint32_t k = 0; k < sc.n_objects; k++) {
+            const ObjRec<T> *ob = sc.objrecs + k;
+            if (COUNT)
+                cnt.aabbw++;
+            if (slab_test<T, true>(ob->lo, ob->hi, rs, tmn, tmx) && tmn < max_distance && tmx > min_distance)
+                cand |= 1u << k;
+        }
+        while (cand) {
+            const uint32_t k = (uint32_t)__builtin_ctz(cand);
+            cand &= cand - 1u;
+            const ObjRec<T> ob = sc.objrecs[k];
+            RayT<T> lr = transform_ray(ray, ob.W2L);
+            traverse_blas<T, ANY, COUNT>(sc, lr, ob, skip_vao, skip_off, is, min_distance, max_distance, cnt);
+            if (ANY && is.hit)
+                return is;
+        }
+        return is;
+    }
     if (COUNT)
         cnt.tlas_nodes++;
     if (!(slab_test<T, true>(sc.tlas_root, sc.tlas_root + 3, rs, tmn, tmx) && tmn < max_distance && tmx > min_distance))
@@ -287,15 +307,13 @@ LPRT_DEV Isect<T> cast_ray(const SceneDev<T> &sc, const RayT<T> &ray, uint32_t s
             uint32_t first = lw >> 1, count = (lw & 1u) + 1u;
             for (uint32_t k = 0; k < count; k++) {
                 LPRT_CHECK_RET(sc, first + k < sc.n_objects, 205, first + k, sc.n_objects, is);
-                const ObjSlot<T> slot = sc.tlas_slots[first + k];
-                LPRT_CHECK_RET(sc, slot.inscene_objid < sc.lim_objects, 206, slot.inscene_objid, sc.lim_objects, is);
+                const ObjRec<T> *ob = sc.objrecs + first + k;
                 if (COUNT)
                     cnt.aabbw++;
-                if (slab_test<T, true>(slot.lo, slot.hi, rs, tmn, tmx) && tmn < max_distance && tmx > min_distance) {
-                    const ObjConst<T> *oc = sc.objects + slot.inscene_objid;
-                    RayT<T> lr = transform_ray(ray, oc->W2L);
-                    traverse_blas<T, ANY, COUNT>(sc, lr, slot.inscene_objid, oc->objectid, skip_vao, skip_off, is,
-                                                 min_distance, max_distance, cnt);
+                if (slab_test<T, true>(ob->lo, ob->hi, rs, tmn, tmx) && tmn < max_distance && tmx > min_distance) {
+                    const ObjRec<T> obv = *ob;
+                    RayT<T> lr = transform_ray(ray, obv.W2L);
+                    traverse_blas<T, ANY, COUNT>(sc, lr, obv, skip_vao, skip_off, is, min_distance, max_distance, cnt);
                     if (ANY && is.hit)
                         return is;
                 }

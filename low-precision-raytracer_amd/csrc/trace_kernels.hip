@@ -102,6 +102,43 @@ template <typename T> __global__ void k_convert_mat4(const float *in, M4<T> *out
     out[i / 16].m[i % 16] = cvt<T>(in[i]);
 }
 
+// ObjRec[s] for TLAS slot s, gathered once per scene/BLAS change
+template <typename T>
+__global__ void k_make_objrecs(const ObjSlot<T> *slots, const ObjConst<T> *objects, const BlasInfo *blas, const T *roots, uint32_t n, uint32_t n_vaos,
+                               ObjRec<T> *out) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n)
+        return;
+    const ObjSlot<T> slot = slots[s];
+    const ObjConst<T> oc = objects[slot.inscene_objid];
+    ObjRec<T> r;
+    for (int k = 0; k < 3; k++) {
+        r.lo[k] = slot.lo[k];
+        r.hi[k] = slot.hi[k];
+    }
+    r.W2L = oc.W2L;
+    r.inscene_objid = slot.inscene_objid;
+    r.vao_index = oc.objectid;
+    BlasInfo bi{};
+    if (oc.objectid < n_vaos)
+        bi = blas[oc.objectid];
+    r.n_tris = bi.n_tris;
+    r.depth = bi.depth;
+    r.tri_base = bi.tri_base;
+    r.inner_base = bi.inner_base;
+    for (int k = 0; k < 3; k++) {
+        r.root_lo[k] = bi.n_tris ? roots[6 * bi.root_base + k] : (T)0;
+        r.root_hi[k] = bi.n_tris ? roots[6 * bi.root_base + 3 + k] : (T)0;
+    }
+    out[s] = r;
+}
+template <typename T>
+void launch_make_objrecs(hipStream_t st, const ObjSlot<T> *slots, const ObjConst<T> *objects, const BlasInfo *blas, const T *roots, uint32_t n,
+                         uint32_t n_vaos, ObjRec<T> *out) {
+    if (n)
+        hipLaunchKernelGGL(k_make_objrecs<T>, dim3((n + 63) / 64), dim3(64), 0, st, slots, objects, blas, roots, n, n_vaos, out);
+}
+
 template <typename T> void launch_convert_objects(hipStream_t st, const lprt_object *in, ObjConst<T> *out, uint32_t n) {
     if (n)
         hipLaunchKernelGGL(k_convert_objects<T>, dim3((n + 63) / 64), dim3(64), 0, st, in, out, n);
@@ -119,6 +156,8 @@ template <typename T> void launch_convert_mat4(hipStream_t st, const float *in, 
         hipLaunchKernelGGL(k_convert_mat4<T>, dim3((n * 16 + 63) / 64), dim3(64), 0, st, in, out, n);
 }
 #define INST(T)                                                                                                        \
+    template void launch_make_objrecs<T>(hipStream_t, const ObjSlot<T> *, const ObjConst<T> *, const BlasInfo *, const T *, uint32_t, uint32_t,    \
+                                         ObjRec<T> *);                                                                 \
     template void launch_convert_objects<T>(hipStream_t, const lprt_object *, ObjConst<T> *, uint32_t);                \
     template void launch_convert_materials<T>(hipStream_t, const lprt_material *, MaterialT<T> *, uint32_t);           \
     template void launch_convert_lights<T>(hipStream_t, const lprt_light *, LightT<T> *, uint32_t);                    \

@@ -49,6 +49,15 @@ template <typename T> struct alignas(16) ObjSlot {
     T lo[3], hi[3];
     uint32_t inscene_objid;
 };
+// Everything a ray needs to enter one object instance, in TLAS (Morton) slot order: the world box (aabbs_W), the
+// world->local transform and the BLAS header + root box.  The reference reaches these through four dependent
+// fetches (aabbs_W[i], inscene_objid[i] -> objects_constant[id] -> objects_bvh[vao] -> nodes[0]; cuda.hpp:544-563, 421-437).
+template <typename T> struct alignas(16) ObjRec {
+    T lo[3], hi[3];           // world-space box
+    T root_lo[3], root_hi[3]; // BLAS root box (object space)
+    M4<T> W2L;
+    uint32_t inscene_objid, vao_index, n_tris, depth, tri_base, inner_base;
+};
 // CUDAObjectConstantData<DataT> (memory.hpp:279-301)
 template <typename T> struct alignas(16) ObjConst {
     M4<T> L2W, W2L;
@@ -75,6 +84,7 @@ template <typename T> struct SceneDev {
     const uint32_t *tlas_leaf;
     const T *tlas_root; // 6 scalars
     const ObjSlot<T> *tlas_slots;
+    const ObjRec<T> *objrecs; // n_objects records in slot order
     uint32_t tlas_depth, n_objects;
     const ObjConst<T> *objects;
     // BLAS
