@@ -412,6 +412,12 @@ template <typename T> struct Impl : CtxBase {
         sc.objrecs = d_objrecs.template as<ObjRec<T>>();
         sc.tlas_depth = tlas.depth;
         sc.n_objects = tlas.n_objects;
+        sc.tlas_mode = tlas.n_objects <= 32u ? 1u : 0u;
+        if (const char *m = std::getenv("LPRT_TLAS_MODE")) { // experiment knob: 0 tree, 1 flat, 2 lockstep
+            uint32_t v = (uint32_t)std::atoi(m);
+            if (v == 0u || tlas.n_objects <= 32u)
+                sc.tlas_mode = v > 2u ? 0u : v;
+        }
         sc.objects = d_objects.template as<ObjConst<T>>();
         sc.blas = geo.d_blas.template as<BlasInfo>();
         sc.blas_roots = geo.d_roots.template as<T>();

@@ -9,6 +9,8 @@
 // B2 replaces SceneBVH::update (rt/trace/scene_bvh.hpp:50-133), rebuilt per frame on the CPU, by a
 //    single-workgroup kernel (LDS bitonic sort + the same tree).
 #include "build.hpp"
+#include <cstdlib>
+#include <string>
 
 namespace lprt {
 
@@ -281,6 +283,107 @@ __global__ void k_radix_scatter(const unsigned long long *keys_in, const uint32_
             vals_out[dst] = val[r];
         }
     }
+}
+
+// ---- median-split ordering (default BLAS builder) -----------------------------------------------------------------
+// The reference splits every node at the object median along the longest axis of its bounds
+// (rt/trace/object_bvh.hpp:111-125).  The same hierarchy is produced here level by level: at depth d every node's
+// range is sorted along the node's own longest axis (16-bit quantised centroid key, stable radix sort with the
+// node's start position as the high digits, so elements never leave their node); the implicit tree then splits each
+// range at l + (r-l)/2.  A plain Morton order (k_morton_keys, LPRT_BLAS_BUILDER=morton) builds 3x faster but its
+// index-median splits cut the Z-curve at arbitrary places: sibling boxes overlap and traversal visited 3.3x more
+// boxes on the 262k-triangle atrium.
+__host__ __device__ inline void segment_at(uint32_t q, uint32_t d, uint32_t n, uint32_t &l, uint32_t &r) {
+    l = 0;
+    r = n;
+    for (uint32_t b = 0; b < d; b++) {
+        uint32_t mid = l + (r - l) / 2;
+        if (q < mid)
+            r = mid;
+        else
+            l = mid;
+    }
+}
+__global__ void k_iota(uint32_t *p, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        p[i] = i;
+}
+// bounds[6*i .. 6*i+5] = (+max,+max,+max,-max,-max,-max) in order-preserving int space
+__global__ void k_init_bounds(int *bounds, uint32_t n) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 6 * n)
+        bounds[i] = (i % 6) < 3 ? 0x7fffffff : (int)0x80000000;
+}
+__global__ void k_seg_bounds(const uint32_t *perm, const float *tri_bounds, const uint32_t *tri_prim, const BlasInfo *blas, uint32_t n_tris,
+                             uint32_t d, int *seg_bounds) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t seg = 0xffffffffu;
+    float lo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, hi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+    if (s < n_tris) {
+        const BlasInfo bi = blas[tri_prim[s]];
+        if (d < bi.depth) {
+            uint32_t l, r;
+            segment_at(s - bi.tri_base, d, bi.n_tris, l, r);
+            seg = bi.tri_base + l;
+            const float *b = tri_bounds + 6 * (size_t)perm[s];
+            for (int k = 0; k < 3; k++) {
+                lo[k] = b[k];
+                hi[k] = b[3 + k];
+            }
+        }
+    }
+    const uint32_t seg0 = __shfl(seg, 0, 64);
+    if (__all(seg == seg0)) { // whole wave inside one node: reduce first
+        if (seg0 == 0xffffffffu)
+            return;
+        for (int off = 32; off > 0; off >>= 1)
+            for (int k = 0; k < 3; k++) {
+                lo[k] = fminf(lo[k], __shfl_xor(lo[k], off, 64));
+                hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off, 64));
+            }
+        if ((threadIdx.x & 63) == 0)
+            for (int k = 0; k < 3; k++) {
+                atomicMin(seg_bounds + 6 * (size_t)seg0 + k, f32_ordered(lo[k]));
+                atomicMax(seg_bounds + 6 * (size_t)seg0 + 3 + k, f32_ordered(hi[k]));
+            }
+    } else if (seg != 0xffffffffu) {
+        for (int k = 0; k < 3; k++) {
+            atomicMin(seg_bounds + 6 * (size_t)seg + k, f32_ordered(lo[k]));
+            atomicMax(seg_bounds + 6 * (size_t)seg + 3 + k, f32_ordered(hi[k]));
+        }
+    }
+}
+__global__ void k_seg_keys(const uint32_t *perm, const float *tri_bounds, const uint32_t *tri_prim, const BlasInfo *blas, uint32_t n_tris, uint32_t d,
+                           const int *seg_bounds, unsigned long long *keys) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_tris)
+        return;
+    const BlasInfo bi = blas[tri_prim[s]];
+    if (d >= bi.depth) { // this primitive's tree is complete: keep the element where it is
+        keys[s] = (unsigned long long)s << 16;
+        return;
+    }
+    uint32_t l, r;
+    segment_at(s - bi.tri_base, d, bi.n_tris, l, r);
+    const uint32_t seg = bi.tri_base + l;
+    float lo[3], hi[3];
+    for (int k = 0; k < 3; k++) {
+        lo[k] = f32_unordered(seg_bounds[6 * (size_t)seg + k]);
+        hi[k] = f32_unordered(seg_bounds[6 * (size_t)seg + 3 + k]);
+    }
+    const float w0 = hi[0] - lo[0], w1 = hi[1] - lo[1], w2 = hi[2] - lo[2];
+    int axis = 0; // strictly longest axis, x on ties (object_bvh.hpp:111-119)
+    if (w1 > w0 && w1 > w2)
+        axis = 1;
+    else if (w2 > w0 && w2 > w1)
+        axis = 2;
+    const float *b = tri_bounds + 6 * (size_t)perm[s];
+    const float c = 0.5f * (b[axis] + b[3 + axis]);
+    const float ext = hi[axis] - lo[axis];
+    const float q = ext > 0.0f ? (c - lo[axis]) / ext : 0.0f;
+    const uint32_t q16 = (uint32_t)fminf(fmaxf(q * 65535.0f, 0.0f), 65535.0f);
+    keys[s] = ((unsigned long long)seg << 16) | q16;
 }
 
 // ---- tree emission ---------------------------------------------------------------------------------
@@ -600,42 +703,60 @@ template <typename T> void GeometryStore<T>::upload(hipStream_t st, const lprt_v
     built = false;
 }
 
+template <typename T> void GeometryStore<T>::radix_sort(hipStream_t st, const std::vector<int> &shifts, int &cur) {
+    const uint32_t n_blocks = (n_tris + RS_TILE - 1) / RS_TILE;
+    for (int shift : shifts) {
+        hipLaunchKernelGGL(k_radix_hist, dim3(n_blocks), dim3(RS_THREADS), 0, st, d_keys[cur].as<unsigned long long>(), n_tris, shift,
+                           d_hist.as<uint32_t>(), n_blocks);
+        hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(RS_THREADS), 0, st, d_hist.as<uint32_t>(), 256 * n_blocks);
+        hipLaunchKernelGGL(k_radix_scatter, dim3(n_blocks), dim3(RS_THREADS), 0, st, d_keys[cur].as<unsigned long long>(),
+                           d_vals[cur].as<uint32_t>(), d_keys[cur ^ 1].as<unsigned long long>(), d_vals[cur ^ 1].as<uint32_t>(), n_tris, shift,
+                           d_hist.as<uint32_t>(), n_blocks);
+        cur ^= 1;
+    }
+}
+
 template <typename T> void GeometryStore<T>::build_blas(hipStream_t st) {
     if (n_tris == 0 || n_vaos == 0) {
         built = true;
         return;
     }
     const uint32_t tb = (n_tris + 255) / 256;
-    // centroid bounds start at (+max, -max) in ordered-int space
-    std::vector<int> init(6 * (size_t)n_vaos);
-    for (uint32_t p = 0; p < n_vaos; p++)
-        for (int k = 0; k < 3; k++) {
-            init[6 * p + k] = 0x7fffffff;
-            init[6 * p + 3 + k] = (int)0x80000000;
-        }
-    LPRT_HIP(hipMemcpyAsync(d_prim_cbounds.ptr, init.data(), sizeof(int) * init.size(), hipMemcpyHostToDevice, st));
-    LPRT_HIP(hipStreamSynchronize(st));
+    const char *bsel = std::getenv("LPRT_BLAS_BUILDER");
+    const bool use_morton = bsel && std::string(bsel) == "morton";
+    hipLaunchKernelGGL(k_init_bounds, dim3((6 * n_vaos + 255) / 256), dim3(256), 0, st, d_prim_cbounds.as<int>(), n_vaos);
     hipLaunchKernelGGL(k_tri_prepare, dim3(tb), dim3(256), 0, st, d_vbo32.as<lprt_vertex>(), d_ebo.as<uint32_t>(), n_tris,
                        d_tri_prim.as<uint32_t>(), d_mf32.as<TriRecF32>(), d_tri_bounds.as<float>(), d_prim_cbounds.as<int>());
-    hipLaunchKernelGGL(k_morton_keys, dim3(tb), dim3(256), 0, st, d_tri_bounds.as<float>(), d_tri_prim.as<uint32_t>(),
-                       d_prim_cbounds.as<int>(), n_tris, d_keys[0].as<unsigned long long>(), d_vals[0].as<uint32_t>());
-    // radix passes over the 30 Morton bits + the primitive bits (key = prim << 32 | morton)
-    uint32_t prim_bits = 0;
-    while ((1u << prim_bits) < n_vaos)
-        prim_bits++;
-    std::vector<int> shifts = {0, 8, 16, 24};
-    for (uint32_t b = 0; b < prim_bits; b += 8)
-        shifts.push_back(32 + (int)b);
-    const uint32_t n_blocks = (n_tris + RS_TILE - 1) / RS_TILE;
     int cur = 0;
-    for (int shift : shifts) {
-        hipLaunchKernelGGL(k_radix_hist, dim3(n_blocks), dim3(RS_THREADS), 0, st, d_keys[cur].as<unsigned long long>(), n_tris,
-                           shift, d_hist.as<uint32_t>(), n_blocks);
-        hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(RS_THREADS), 0, st, d_hist.as<uint32_t>(), 256 * n_blocks);
-        hipLaunchKernelGGL(k_radix_scatter, dim3(n_blocks), dim3(RS_THREADS), 0, st, d_keys[cur].as<unsigned long long>(),
-                           d_vals[cur].as<uint32_t>(), d_keys[cur ^ 1].as<unsigned long long>(), d_vals[cur ^ 1].as<uint32_t>(),
-                           n_tris, shift, d_hist.as<uint32_t>(), n_blocks);
-        cur ^= 1;
+    if (use_morton) {
+        hipLaunchKernelGGL(k_morton_keys, dim3(tb), dim3(256), 0, st, d_tri_bounds.as<float>(), d_tri_prim.as<uint32_t>(),
+                           d_prim_cbounds.as<int>(), n_tris, d_keys[0].as<unsigned long long>(), d_vals[0].as<uint32_t>());
+        // radix passes over the 30 Morton bits + the primitive bits (key = prim << 32 | morton)
+        uint32_t prim_bits = 0;
+        while ((1u << prim_bits) < n_vaos)
+            prim_bits++;
+        std::vector<int> shifts = {0, 8, 16, 24};
+        for (uint32_t b = 0; b < prim_bits; b += 8)
+            shifts.push_back(32 + (int)b);
+        radix_sort(st, shifts, cur);
+    } else {
+        uint32_t pos_bits = 1;
+        while ((1ull << pos_bits) < n_tris)
+            pos_bits++;
+        std::vector<int> shifts = {0, 8};
+        for (uint32_t b = 0; b < pos_bits; b += 8)
+            shifts.push_back(16 + (int)b);
+        d_seg_bounds.reserve(sizeof(int) * 6 * (size_t)n_tris);
+        hipLaunchKernelGGL(k_iota, dim3(tb), dim3(256), 0, st, d_vals[cur].as<uint32_t>(), n_tris);
+        for (uint32_t d = 0; d < max_depth; d++) {
+            hipLaunchKernelGGL(k_init_bounds, dim3((6 * n_tris + 255) / 256), dim3(256), 0, st, d_seg_bounds.as<int>(), n_tris);
+            hipLaunchKernelGGL(k_seg_bounds, dim3(tb), dim3(256), 0, st, d_vals[cur].as<uint32_t>(), d_tri_bounds.as<float>(),
+                               d_tri_prim.as<uint32_t>(), d_blas.as<BlasInfo>(), n_tris, d, d_seg_bounds.as<int>());
+            hipLaunchKernelGGL(k_seg_keys, dim3(tb), dim3(256), 0, st, d_vals[cur].as<uint32_t>(), d_tri_bounds.as<float>(),
+                               d_tri_prim.as<uint32_t>(), d_blas.as<BlasInfo>(), n_tris, d, d_seg_bounds.as<int>(),
+                               d_keys[cur].as<unsigned long long>());
+            radix_sort(st, shifts, cur);
+        }
     }
     sorted_buf = cur;
     hipLaunchKernelGGL(k_emit_triangles<T>, dim3(tb), dim3(256), 0, st, d_vals[cur].as<uint32_t>(), d_mf32.as<TriRecF32>(),

@@ -142,6 +142,8 @@ template <typename T> LPRT_DEV V4<T> mul(const M4<T> &a, V4<T> v) {
 template <typename T> LPRT_DEV V3<T> xform_dir(const M4<T> &a, V3<T> d) { return xyz(mul(a, mk4(d.x, d.y, d.z, (T)0))); }
 template <typename T> LPRT_DEV V3<T> xform_pos(const M4<T> &a, V3<T> p) { // to_vec3_as_pos: divide by w (matrix.hpp:599-605)
     V4<T> r = mul(a, mk4(p.x, p.y, p.z, (T)1));
+    if (r.w == (T)1) // affine transforms: x / 1 == x exactly, skip three IEEE divisions
+        return {r.x, r.y, r.z};
     return {tdiv(r.x, r.w), tdiv(r.y, r.w), tdiv(r.z, r.w)};
 }
 

@@ -186,13 +186,12 @@ LPRT_DEV void leaf_range_dev(uint32_t k, uint32_t D, uint32_t n, uint32_t &l, ui
 
 // ---- T4: BLAS traversal (replaces search_intersection_in_object, cuda.hpp:415-504) -----------------
 template <typename T, bool ANY, bool COUNT>
-LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, const ObjRec<T> &ob, uint32_t skip_vao, uint32_t skip_off, Isect<T> &is,
-                            T min_distance, T max_distance, Cnt<COUNT> &cnt) {
+LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, const RaySlab<T> &rs, const ObjRec<T> &ob, uint32_t skip_vao,
+                            uint32_t skip_off, Isect<T> &is, T min_distance, T max_distance, Cnt<COUNT> &cnt) {
     if (COUNT)
         cnt.objects++;
     if (ob.n_tris == 0)
         return;
-    const RaySlab<T> rs = make_slab(ray);
     T tmn, tmx;
     if (COUNT)
         cnt.blas_nodes++;
@@ -201,9 +200,24 @@ LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, const Obj
     const InnerNode<T> *inner = sc.blas_inner + ob.inner_base;
     const uint32_t D = ob.depth;
     const bool skip_here = (ob.vao_index == skip_vao);
+    if (D <= 1) {
+        // 1-3 triangles (a quad is two): the child boxes would cost more than the triangle tests they could save
+        for (uint32_t k = 0; k < ob.n_tris; k++) {
+            uint32_t rec = ob.tri_base + k;
+            if (skip_here && sc.tris[rec].inobject_offset == skip_off)
+                continue;
+            tri_test<T, COUNT>(sc, rec, ray, ob.inscene_objid, is, min_distance, max_distance, cnt);
+            if (ANY && is.hit)
+                return;
+        }
+        return;
+    }
+    // "while-while": every lane first walks inner nodes until it stands on a leaf (or runs out of work), then the
+    // whole wave tests triangles; the two code paths are not interleaved per iteration.
     uint32_t i = 1, c = 0, pending = 0;
-    for (;;) {
-        if (c < D) {
+    bool alive = true;
+    while (alive) {
+        while (c < D) {
             LPRT_CHECK(sc, ob.inner_base + i - 1 < sc.lim_inner, 203, ob.inner_base + i - 1, sc.lim_inner);
             const InnerNode<T> nd = inner[i - 1];
             if (COUNT)
@@ -217,9 +231,20 @@ LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, const Obj
                     pending |= 1u << (c + 1);
                 i = 2 * i + first;
                 c++;
-                continue;
+            } else {
+                if (!pending) {
+                    alive = false;
+                    break;
+                }
+                uint32_t d = 31u - (uint32_t)__builtin_clz(pending);
+                pending ^= 1u << d;
+                i = (i >> (c - d)) ^ 1u;
+                c = d;
             }
-        } else {
+        }
+        if (!alive)
+            break;
+        {
             uint32_t l, r;
             leaf_range_dev(i - (1u << D), D, ob.n_tris, l, r);
             for (uint32_t k = l; k < r; k++) {
@@ -232,7 +257,7 @@ LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, const Obj
             }
         }
         if (!pending)
-            return;
+            break;
         uint32_t d = 31u - (uint32_t)__builtin_clz(pending);
         pending ^= 1u << d;
         i = (i >> (c - d)) ^ 1u;
@@ -256,10 +281,10 @@ LPRT_DEV Isect<T> cast_ray(const SceneDev<T> &sc, const RayT<T> &ray, uint32_t s
         return is;
     const RaySlab<T> rs = make_slab(ray);
     T tmn, tmx;
-    if (sc.n_objects <= 32u) {
+    if (sc.tlas_mode == 1u) {
         // Small scenes (the Cornell box has 8 instances): a tree over a handful of mutually overlapping boxes costs ~2n
-        // slab tests per ray; scan the n world boxes instead.  The loop is wave-uniform, so the boxes arrive through
-        // scalar loads, and the object phase below starts with every lane's candidate list complete.
+        // slab tests per ray; scan the n world boxes instead.  The scan loop is wave-uniform, so the boxes arrive through
+        // scalar loads, and the object phase starts with every lane's candidate list complete.
         uint32_t cand = 0;
         for (uint32_t k = 0; k < sc.n_objects; k++) {
             const ObjRec<T> *ob = sc.objrecs + k;
@@ -272,10 +297,39 @@ LPRT_DEV Isect<T> cast_ray(const SceneDev<T> &sc, const RayT<T> &ray, uint32_t s
             const uint32_t k = (uint32_t)__builtin_ctz(cand);
             cand &= cand - 1u;
             const ObjRec<T> ob = sc.objrecs[k];
-            RayT<T> lr = transform_ray(ray, ob.W2L);
-            traverse_blas<T, ANY, COUNT>(sc, lr, ob, skip_vao, skip_off, is, min_distance, max_distance, cnt);
+            if (ob.identity) {
+                traverse_blas<T, ANY, COUNT>(sc, ray, rs, ob, skip_vao, skip_off, is, min_distance, max_distance, cnt);
+            } else {
+                const RayT<T> lr = transform_ray(ray, ob.W2L);
+                const RaySlab<T> lrs = make_slab(lr);
+                traverse_blas<T, ANY, COUNT>(sc, lr, lrs, ob, skip_vao, skip_off, is, min_distance, max_distance, cnt);
+            }
             if (ANY && is.hit)
                 return is;
+        }
+        return is;
+    }
+    if (sc.tlas_mode == 2u) {
+        // Variant: the same scan in LOCKSTEP across the wave (k wave-uniform: object record, BLAS header and, for 1-3
+        // triangle primitives, the triangle records are scalar loads; lanes whose ray misses box k sit the step out).
+        for (uint32_t k = 0; k < sc.n_objects; k++) {
+            const ObjRec<T> *ob = sc.objrecs + k;
+            if (COUNT)
+                cnt.aabbw++;
+            bool enter = slab_test<T, true>(ob->lo, ob->hi, rs, tmn, tmx) && tmn < max_distance && tmx > min_distance;
+            if (ANY)
+                enter = enter && !is.hit;
+            if (!__builtin_amdgcn_ballot_w64(enter))
+                continue; // no ray of this wave touches object k
+            if (enter) {
+                if (ob->identity) {
+                    traverse_blas<T, ANY, COUNT>(sc, ray, rs, *ob, skip_vao, skip_off, is, min_distance, max_distance, cnt);
+                } else {
+                    const RayT<T> lr = transform_ray(ray, ob->W2L);
+                    const RaySlab<T> lrs = make_slab(lr);
+                    traverse_blas<T, ANY, COUNT>(sc, lr, lrs, *ob, skip_vao, skip_off, is, min_distance, max_distance, cnt);
+                }
+            }
         }
         return is;
     }
@@ -312,8 +366,9 @@ LPRT_DEV Isect<T> cast_ray(const SceneDev<T> &sc, const RayT<T> &ray, uint32_t s
                     cnt.aabbw++;
                 if (slab_test<T, true>(ob->lo, ob->hi, rs, tmn, tmx) && tmn < max_distance && tmx > min_distance) {
                     const ObjRec<T> obv = *ob;
-                    RayT<T> lr = transform_ray(ray, obv.W2L);
-                    traverse_blas<T, ANY, COUNT>(sc, lr, obv, skip_vao, skip_off, is, min_distance, max_distance, cnt);
+                    const RayT<T> lr = transform_ray(ray, obv.W2L);
+                    const RaySlab<T> lrs = make_slab(lr);
+                    traverse_blas<T, ANY, COUNT>(sc, lr, lrs, obv, skip_vao, skip_off, is, min_distance, max_distance, cnt);
                     if (ANY && is.hit)
                         return is;
                 }

@@ -57,6 +57,8 @@ template <typename T> struct alignas(16) ObjRec {
     T root_lo[3], root_hi[3]; // BLAS root box (object space)
     M4<T> W2L;
     uint32_t inscene_objid, vao_index, n_tris, depth, tri_base, inner_base;
+    uint32_t identity; // W2L is exactly the identity: the local ray is the world ray (x*1 + y*0 + ... is exact)
+    uint32_t pad[3];
 };
 // CUDAObjectConstantData<DataT> (memory.hpp:279-301)
 template <typename T> struct alignas(16) ObjConst {
@@ -86,6 +88,7 @@ template <typename T> struct SceneDev {
     const ObjSlot<T> *tlas_slots;
     const ObjRec<T> *objrecs; // n_objects records in slot order
     uint32_t tlas_depth, n_objects;
+    uint32_t tlas_mode, tlas_pad; // 0: tree, 1: flat scan + per-lane candidate list (<= 32 objects), 2: lockstep scan
     const ObjConst<T> *objects;
     // BLAS
     const BlasInfo *blas;
