@@ -66,43 +66,50 @@ def barrier_sync(world):
     torch.cuda.synchronize()
 
 
-def measure(prec, sc, W, H, spp, steps, warmup, rank, world, device, stage_timing=True):
+def measure(prec, sc, W, H, spp, steps, warmup, rank, world, device, stage_timing=True, backend="nccl"):
     """Times `steps` frames; returns a dict (identical on every rank for the reduced fields)."""
     win_b, win_e = lp_dist.window_rows(H, world, rank)
     r = lprt_amd.Renderer(W, H, prec, device=device, row_begin=win_b, row_end=win_e)
     r.set_stream(torch.cuda.current_stream().cuda_stream)
-    frame = lp_dist.ShardedFrame(W, H, rank, world, torch.device("cuda", device))
+    frame = lp_dist.ShardedFrame(W, H, rank, world, torch.device("cuda", device), backend=backend)
     ptr, first_row, n_rows = frame.target()
     r.set_output_target(ptr, first_row, n_rows)
     r.load_scene(sc)
     fs = abi.default_settings(spp=spp, gi_on=True, svgf=True)
 
+    last = {}
+
     def step():
         r.set_scene(sc)   # per-frame RDScene hand-over + TLAS rebuild (rt/rtrt/cuda.hpp:662-710)
         r.render(fs)
-        frame.all_gather()
+        last["image"] = frame.all_gather()
 
-    # rays of one whole frame and per-kernel work counters: one instrumented, untimed frame of the full image
+    # rays of one whole frame (full image, rank 0) and per-kernel work counters of THIS rank's launches: one
+    # instrumented, untimed frame each
     frame_rays, stage_counters = None, {}
     if rank == 0:
-        full = r if world == 1 else lprt_amd.Renderer(W, H, prec, device=device)
-        if world > 1:
-            full.load_scene(sc)
-        full.enable_counters(True)
-        full.reset_counters()
-        full.set_scene(sc)
-        full.render(fs)
-        full.synchronize()
-        frame_rays = full.counters()["rays"]
+        r.enable_counters(True)
+        r.reset_counters()
+        r.set_scene(sc)
+        r.render(fs)
+        r.synchronize()
         for st in ("primary", "trace_di1", "trace_gi", "trace_di2"):
-            stage_counters[st] = full.stage_counters(st)
-        full.enable_counters(False)
-        if world > 1:
+            stage_counters[st] = r.stage_counters(st)
+        frame_rays = r.counters()["rays"]
+        r.enable_counters(False)
+        r.reset_history()
+        if world > 1:  # the strip + halo is not the frame: count the rays of the whole image once
+            full = lprt_amd.Renderer(W, H, prec, device=device)
+            full.load_scene(sc)
+            full.enable_counters(True)
+            full.reset_counters()
+            full.render(fs)
+            full.synchronize()
+            frame_rays = full.counters()["rays"]
             full.close()
-        else:
-            r.reset_history()
+    cdev = f"cuda:{device}" if backend == "nccl" else "cpu"
     if world > 1:
-        t = torch.tensor([frame_rays or 0], dtype=torch.int64, device=f"cuda:{device}")
+        t = torch.tensor([frame_rays or 0], dtype=torch.int64, device=cdev)
         torch.distributed.broadcast(t, 0)
         frame_rays = int(t.item())
 
@@ -117,12 +124,12 @@ def measure(prec, sc, W, H, spp, steps, warmup, rank, world, device, stage_timin
     barrier_sync(world)
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{device}")
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     stage = r.stage_times() if stage_timing else {}
     r.enable_stage_timing(False)
-    out_ok = bool(torch.isfinite(frame.image).all().item())
+    out_ok = bool(torch.isfinite(last["image"]).all().item()) and bool((last["image"][..., 3] == 1).all().item())
     res = dict(dt=dt, ms_per_step=1e3 * dt / steps, frames_per_s=steps / dt, frame_rays=frame_rays,
                mrays_per_s=frame_rays * steps / dt / 1e6, stage=stage, stage_counters=stage_counters,
                finite=out_ok, window_rows=[win_b, win_e])
@@ -193,6 +200,8 @@ def main():
     ap.add_argument("--no-fp16", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (RCCL over xGMI) | gloo (rehearsal: gathers through host memory)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank renders on GPU 0")
     args = ap.parse_args()
 
     rank, world, local = dist_info()
@@ -201,16 +210,21 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if args.single_device:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            torch.distributed.init_process_group(args.backend)
 
     sc = scenes.SCENES[args.scene]()
     W, H, spp = args.width, args.height, args.spp
-    res32 = measure(abi.F32, sc, W, H, spp, args.steps, args.warmup, rank, world, local, not args.no_stage_timing)
+    res32 = measure(abi.F32, sc, W, H, spp, args.steps, args.warmup, rank, world, local, not args.no_stage_timing, args.backend)
     res16 = None if args.no_fp16 else measure(abi.F16, sc, W, H, spp, args.steps, args.warmup, rank, world, local,
-                                               not args.no_stage_timing)
+                                               not args.no_stage_timing, args.backend)
     if rank == 0:
         win_rows = res32["window_rows"][1] - res32["window_rows"][0]
         out = {

@@ -31,36 +31,53 @@ def equal_strips(height, world_size):
 
 
 class ShardedFrame:
-    """Owns the gathered RGBA32F image of one rank and performs the per-frame all-gather."""
+    """Owns one rank's strip buffer and the gathered RGBA32F image, and performs the per-frame all-gather.
 
-    def __init__(self, width, height, rank, world_size, device):
+    The renderer writes this rank's rows into `send` (lprt_set_output_target); `all_gather()` completes `image` on
+    every rank.  Equal strips (H % N == 0: 1080p and 4K on 1/2/4/8 GPUs) gather straight into the image; ragged
+    strips go through padded per-rank slots.  backend "nccl" (= RCCL) gathers device tensors over xGMI; "gloo" (CPU
+    rehearsal) stages through host memory.
+    """
+
+    def __init__(self, width, height, rank, world_size, device, backend="nccl"):
         import torch
         self.torch = torch
         self.W, self.H, self.rank, self.world = width, height, rank, world_size
-        self.device = device
+        self.device, self.backend = device, backend
         self.begin, self.end = strip_rows(height, world_size, rank)
         self.win_begin, self.win_end = window_rows(height, world_size, rank)
         self.image = torch.zeros((height, width, 4), dtype=torch.float32, device=device)
         self.equal = equal_strips(height, world_size)
-        if not self.equal:  # ragged strips: gather through padded per-rank buffers
-            self.max_rows = -(-height // world_size)
-            self.send = torch.zeros((self.max_rows, width, 4), dtype=torch.float32, device=device)
+        self.max_rows = -(-height // world_size)
+        rows = (self.end - self.begin) if self.equal else self.max_rows
+        self.send = torch.zeros((rows, width, 4), dtype=torch.float32, device=device)
+        if not self.equal:
             self.recv = torch.zeros((world_size, self.max_rows, width, 4), dtype=torch.float32, device=device)
 
     def target(self):
         """(device pointer, first_row, n_rows) for lprt_set_output_target."""
-        if self.equal:
-            return self.image[self.begin:self.end].data_ptr(), self.begin, self.end - self.begin
         return self.send.data_ptr(), self.begin, self.end - self.begin
 
     def all_gather(self):
         import torch.distributed as dist
+        torch = self.torch
         if self.world == 1:
-            return self.image
+            return self.send  # one GPU: the strip is the frame
+        staged = self.backend != "nccl" and self.send.is_cuda
         if self.equal:
-            dist.all_gather_into_tensor(self.image.view(-1), self.image[self.begin:self.end].reshape(-1))
+            if staged:
+                out = torch.empty(self.image.shape, dtype=torch.float32)
+                dist.all_gather_into_tensor(out.view(-1), self.send.cpu().view(-1))
+                self.image.copy_(out)
+            else:
+                dist.all_gather_into_tensor(self.image.view(-1), self.send.view(-1))
         else:
-            dist.all_gather_into_tensor(self.recv.view(-1), self.send.view(-1))
+            if staged:
+                out = torch.empty(self.recv.shape, dtype=torch.float32)
+                dist.all_gather_into_tensor(out.view(-1), self.send.cpu().view(-1))
+                self.recv.copy_(out)
+            else:
+                dist.all_gather_into_tensor(self.recv.view(-1), self.send.view(-1))
             for r in range(self.world):
                 b, e = strip_rows(self.H, self.world, r)
                 self.image[b:e].copy_(self.recv[r, :e - b])

@@ -23,17 +23,14 @@ def _worker(rank, world, port, H, W, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     tdist.init_process_group("gloo", rank=rank, world_size=world)
-    frame = dist.ShardedFrame(W, H, rank, world, torch.device("cpu"))
+    frame = dist.ShardedFrame(W, H, rank, world, torch.device("cpu"), backend="gloo")
     # each rank "renders" its strip: value encodes (row, col, channel) so misplaced rows are detected
     b, e = frame.begin, frame.end
     rows = torch.arange(b, e, dtype=torch.float32).view(-1, 1, 1)
     cols = torch.arange(W, dtype=torch.float32).view(1, -1, 1)
     ch = torch.arange(4, dtype=torch.float32).view(1, 1, -1)
     strip = rows * 1000 + cols * 4 + ch
-    if frame.equal:
-        frame.image[b:e] = strip
-    else:
-        frame.send[:e - b] = strip
+    frame.send[:e - b] = strip
     img = frame.all_gather()
     t = torch.tensor([0.1 * (rank + 1)], dtype=torch.float64)
     tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
