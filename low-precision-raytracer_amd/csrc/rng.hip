@@ -21,7 +21,6 @@ struct XorMat {
     uint32_t col[160][8];
 };
 
-// dst[(s*64 + j) - dst_first] = P[j] * src[s].  One block = 64 consecutive s x 16 consecutive j; a wave owns 4 j.
 // level-3 source vectors (host-computed), passed by value: no copy, no sync.  Up to RNG_MAX_BATCH seeds per launch
 // (gridDim.z) x up to 16 vectors each (frames up to 4.19 Mpixel); larger frames go one seed per launch (64 vectors).
 constexpr int RNG_MAX_BATCH = 8;
@@ -32,26 +31,33 @@ struct TopVectors {
     uint32_t v[5][64];
 };
 
-// dst[(s*64 + j) - dst_first] = P[j] * src[s].  One block = 64 consecutive s x 16 consecutive j; a wave owns 4 j.
+// dst[(s*64 + j) - dst_first] = P[j] * src[s].  One block = 128 consecutive s x 16 consecutive j; a wave owns 4 j and
+// every lane carries TWO source vectors (s, s + 64), so each column read from LDS serves two matvecs.
 // The wave's current matrix (5 KB) is staged in LDS with vector loads and its columns are then read back as
 // wave-uniform broadcasts: scalar loads of the columns (the obvious form) are limited by scalar-cache fills.
+// acc ^= column & mask is ONE v_bitop3_b32 (truth table 0x78 = a ^ (b & c)).
 // blockIdx.z = seed of a batch: src / dst planes of seed z start at z * src_seed_stride / z * dst_seed_stride.
+constexpr int RNG_S = 128; // sources per block
+LPRT_DEV uint32_t xor_and(uint32_t acc, uint32_t col, uint32_t mask) { return __builtin_amdgcn_bitop3_b32(acc, col, mask, 0x78); }
 template <int TOP>
 __global__ void __launch_bounds__(256) k_rng_expand(const XorMat *__restrict__ P, const uint32_t *__restrict__ src, TopBatch topb, TopVectors top1,
                                                     uint32_t n_src, uint32_t src_stride, uint32_t src_seed_stride, uint32_t *__restrict__ dst,
                                                     uint32_t dst_first, uint32_t dst_count, uint32_t dst_stride, uint32_t dst_seed_stride) {
     __shared__ uint4 mat[4][160 * 2]; // [wave][column][8 words]
-    __shared__ uint32_t tile[5][64][17];
+    __shared__ uint32_t tile[5][RNG_S][17];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t s = blockIdx.x * 64 + lane;
+    const uint32_t sA = blockIdx.x * RNG_S + lane, sB = sA + 64;
     const uint32_t jbase = blockIdx.y * 16;
     const uint32_t z = blockIdx.z;
     src += (size_t)z * src_seed_stride;
     dst += (size_t)z * dst_seed_stride;
-    uint32_t v[5] = {0, 0, 0, 0, 0};
-    if (s < n_src)
-        for (int k = 0; k < 5; k++)
-            v[k] = TOP == 2 ? topb.v[z][k][s & 15] : (TOP == 1 ? top1.v[k][s & 63] : src[k * src_stride + s]);
+    uint32_t va[5] = {0, 0, 0, 0, 0}, vb[5] = {0, 0, 0, 0, 0};
+    for (int k = 0; k < 5; k++) {
+        if (sA < n_src)
+            va[k] = TOP == 2 ? topb.v[z][k][sA & 15] : (TOP == 1 ? top1.v[k][sA & 63] : src[k * src_stride + sA]);
+        if (sB < n_src)
+            vb[k] = TOP == 2 ? topb.v[z][k][sB & 15] : (TOP == 1 ? top1.v[k][sB & 63] : src[k * src_stride + sB]);
+    }
     for (uint32_t jj = 0; jj < 4; jj++) {
         const uint32_t jl = wave * 4 + jj; // 0..15 within the block
         const uint4 *m = reinterpret_cast<const uint4 *>(P + jbase + jl);
@@ -60,20 +66,26 @@ __global__ void __launch_bounds__(256) k_rng_expand(const XorMat *__restrict__ P
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+        uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0;
 #pragma unroll
         for (int w = 0; w < 5; w++) {
-            const uint32_t bits = v[w];
+            const uint32_t bitsa = va[w], bitsb = vb[w];
 #pragma unroll 8
             for (int b = 0; b < 32; b++) {
                 const uint4 c03 = mat[wave][2 * (w * 32 + b)];
                 const uint32_t c4 = mat[wave][2 * (w * 32 + b) + 1].x;
-                const uint32_t mask = (uint32_t)__builtin_amdgcn_sbfe((int)bits, b, 1); // 0 or ~0
-                a0 ^= c03.x & mask;
-                a1 ^= c03.y & mask;
-                a2 ^= c03.z & mask;
-                a3 ^= c03.w & mask;
-                a4 ^= c4 & mask;
+                const uint32_t ma = (uint32_t)__builtin_amdgcn_sbfe((int)bitsa, b, 1); // 0 or ~0
+                const uint32_t mb = (uint32_t)__builtin_amdgcn_sbfe((int)bitsb, b, 1);
+                a0 = xor_and(a0, c03.x, ma);
+                a1 = xor_and(a1, c03.y, ma);
+                a2 = xor_and(a2, c03.z, ma);
+                a3 = xor_and(a3, c03.w, ma);
+                a4 = xor_and(a4, c4, ma);
+                b0 = xor_and(b0, c03.x, mb);
+                b1 = xor_and(b1, c03.y, mb);
+                b2 = xor_and(b2, c03.z, mb);
+                b3 = xor_and(b3, c03.w, mb);
+                b4 = xor_and(b4, c4, mb);
             }
         }
         tile[0][lane][jl] = a0;
@@ -81,13 +93,18 @@ __global__ void __launch_bounds__(256) k_rng_expand(const XorMat *__restrict__ P
         tile[2][lane][jl] = a2;
         tile[3][lane][jl] = a3;
         tile[4][lane][jl] = a4;
+        tile[0][lane + 64][jl] = b0;
+        tile[1][lane + 64][jl] = b1;
+        tile[2][lane + 64][jl] = b2;
+        tile[3][lane + 64][jl] = b3;
+        tile[4][lane + 64][jl] = b4;
         __builtin_amdgcn_wave_barrier(); // the next staging overwrites mat[wave]: all lanes must be done reading
     }
     __syncthreads();
-    // coalesced write-out: for each of the 64 sources, 16 consecutive destinations
-    for (uint32_t e = threadIdx.x; e < 64 * 16; e += 256) {
+    // coalesced write-out: for each of the 128 sources, 16 consecutive destinations
+    for (uint32_t e = threadIdx.x; e < RNG_S * 16; e += 256) {
         const uint32_t sl = e >> 4, jl = e & 15;
-        const uint32_t ss = blockIdx.x * 64 + sl;
+        const uint32_t ss = blockIdx.x * RNG_S + sl;
         if (ss >= n_src)
             continue;
         const uint32_t n = ss * 64 + jbase + jl;
@@ -225,15 +242,15 @@ void RngStore::generate(hipStream_t st, const uint64_t *seeds, uint32_t n_seeds,
         }
         uint32_t *out = planes + (size_t)done * 5 * count;
         if (n3 <= 16)
-            hipLaunchKernelGGL(k_rng_expand<2>, dim3((n3 + 63) / 64, 4, batch), dim3(256), 0, st, mats + 128, (const uint32_t *)nullptr, topb, top1, n3,
+            hipLaunchKernelGGL(k_rng_expand<2>, dim3((n3 + RNG_S - 1) / RNG_S, 4, batch), dim3(256), 0, st, mats + 128, (const uint32_t *)nullptr, topb, top1, n3,
                                0u, 0u, d_w2.as<uint32_t>(), 0u, w2_stride, w2_stride, 5 * w2_stride);
         else
-            hipLaunchKernelGGL(k_rng_expand<1>, dim3((n3 + 63) / 64, 4, batch), dim3(256), 0, st, mats + 128, (const uint32_t *)nullptr, topb, top1, n3,
+            hipLaunchKernelGGL(k_rng_expand<1>, dim3((n3 + RNG_S - 1) / RNG_S, 4, batch), dim3(256), 0, st, mats + 128, (const uint32_t *)nullptr, topb, top1, n3,
                                0u, 0u, d_w2.as<uint32_t>(), 0u, w2_stride, w2_stride, 5 * w2_stride);
-        hipLaunchKernelGGL(k_rng_expand<0>, dim3((n2 + 63) / 64, 4, batch), dim3(256), 0, st, mats + 64, d_w2.as<uint32_t>(), topb, top1, n2, w2_stride,
+        hipLaunchKernelGGL(k_rng_expand<0>, dim3((n2 + RNG_S - 1) / RNG_S, 4, batch), dim3(256), 0, st, mats + 64, d_w2.as<uint32_t>(), topb, top1, n2, w2_stride,
                            5 * w2_stride, d_w1.as<uint32_t>(), 0u, w1_stride, w1_stride, 5 * w1_stride);
         // last level only for the L1 vectors that cover [first, first + count)
-        hipLaunchKernelGGL(k_rng_expand<0>, dim3((s_end - s_begin + 63) / 64, 4, batch), dim3(256), 0, st, mats, d_w1.as<uint32_t>() + s_begin, topb,
+        hipLaunchKernelGGL(k_rng_expand<0>, dim3((s_end - s_begin + RNG_S - 1) / RNG_S, 4, batch), dim3(256), 0, st, mats, d_w1.as<uint32_t>() + s_begin, topb,
                            top1, s_end - s_begin, w1_stride, 5 * w1_stride, out, first - s_begin * 64, count, count, 5 * count);
         done += batch;
     }
