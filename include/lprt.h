@@ -246,13 +246,16 @@ int lprt_upload_geometry(lprt_ctx *ctx, const lprt_vertex *vbo, uint32_t n_verti
 /* Replaces RDResource::materials + CUDARenderGIData::refresh_materials (rt/rtrt/cuda.hpp:749-755). */
 int lprt_upload_materials(lprt_ctx *ctx, const lprt_material *materials, uint32_t n_materials);
 
-/* Replaces RDTexture(data, w, h, sRGB) (rt/rtrt/memory.hpp:334-369): RGBA8, bilinear, wrap. */
+/* Replaces RDTexture(data, w, h, sRGB) (rt/rtrt/memory.hpp:334-369): tightly packed RGBA8 rows, sampled with
+ * normalised coordinates, wrap addressing, bilinear filtering and (srgb != 0) an sRGB decode per texel.  The handle
+ * goes into lprt_material.tex_color / lprt_skybox.texture; upload textures before the materials that name them. */
 int lprt_upload_texture(lprt_ctx *ctx, const uint8_t *rgba8, uint32_t width, uint32_t height,
                         uint32_t srgb, uint32_t *out_handle);
 
 /* Replaces ObjectBVH<DataT>(positions, indices) for every primitive (rt/trace/object_bvh.hpp:49-63,
- * called at rt/rtrt/loader.cu:434) + fill_objects_bvh (rt/rtrt/cuda.hpp:767-773): GPU build
- * (Morton codes, LSD radix sort, implicit median hierarchy, bottom-up refit). */
+ * called at rt/rtrt/loader.cu:434) + fill_objects_bvh (rt/rtrt/cuda.hpp:767-773): GPU build, level by level
+ * (widest-axis median split of every segment by an LSD radix sort of centroid keys, implicit heap-ordered
+ * hierarchy, bottom-up boxes). */
 int lprt_build_blas(lprt_ctx *ctx);
 
 /* ---- per-frame scene (scene-manager side of the boundary) --------------------------------- */
@@ -310,6 +313,10 @@ int lprt_get_blas_info(lprt_ctx *ctx, uint32_t vao_index, uint32_t *n_triangles,
                        uint32_t *depth);
 int lprt_read_blas_order(lprt_ctx *ctx, uint32_t vao_index, uint32_t *tri_order, uint32_t n);
 int lprt_read_blas_boxes(lprt_ctx *ctx, uint32_t vao_index, float *boxes6, uint32_t n_nodes);
+
+/* Test hook: the texture fetch shade() makes (normalised coordinates, wrap, bilinear with 1.8 fixed-point weights,
+ * optional sRGB decode) at uv[n][2]; rgba = [n][4] floats. */
+int lprt_debug_sample_texture(lprt_ctx *ctx, uint32_t handle, const float *uv, uint32_t n, float *rgba);
 
 /* Test hook: xorwow state words v[0..4], d of curand_init(seed, n, 0) for global pixels n in
  * [first, first + count), as the frame kernels receive them; out = [count][6] uint32. */

@@ -1,6 +1,7 @@
 // C-ABI entry points (include/lprt.h) over the templated renderer implementation.
 #include "build.hpp"
 #include "kernels.hpp"
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -10,8 +11,41 @@
 
 namespace lprt {
 
+// RDTexture owners (memory.hpp:334-369): RGBA8 texel arrays + the descriptor table the kernels index by handle
+struct TextureStore {
+    std::vector<std::unique_ptr<DevBuf>> texels;
+    std::vector<Texture> host;
+    DevBuf table, lut;
+    uint32_t add(hipStream_t st, const uint8_t *rgba8, uint32_t w, uint32_t h, bool srgb) {
+        if (!lut.ptr) {
+            float t[256];
+            for (int i = 0; i < 256; i++) { // IEC 61966-2-1 decode, evaluated in double, rounded once
+                double c = i / 255.0;
+                t[i] = (float)(c <= 0.04045 ? c / 12.92 : std::pow((c + 0.055) / 1.055, 2.4));
+            }
+            lut.reserve(sizeof(t));
+            LPRT_HIP(hipMemcpyAsync(lut.ptr, t, sizeof(t), hipMemcpyHostToDevice, st));
+            LPRT_HIP(hipStreamSynchronize(st));
+        }
+        std::unique_ptr<DevBuf> b(new DevBuf);
+        const size_t bytes = (size_t)w * h * 4;
+        b->reserve(bytes);
+        LPRT_HIP(hipMemcpyAsync(b->ptr, rgba8, bytes, hipMemcpyHostToDevice, st));
+        host.push_back(Texture{b->as<uint32_t>(), w, h, srgb ? 1u : 0u, 0u});
+        texels.push_back(std::move(b));
+        DevBuf fresh; // the table grows by reallocation; frames in flight still read the old one until the sync below
+        fresh.reserve(sizeof(Texture) * host.size());
+        LPRT_HIP(hipMemcpyAsync(fresh.ptr, host.data(), sizeof(Texture) * host.size(), hipMemcpyHostToDevice, st));
+        LPRT_HIP(hipStreamSynchronize(st));
+        std::swap(table.ptr, fresh.ptr);
+        std::swap(table.bytes, fresh.bytes);
+        return (uint32_t)host.size() - 1u;
+    }
+};
+
 struct CtxBase {
     std::string error;
+    TextureStore tex;
     int device = 0;
     Window win{};
     lprt_precision precision = LPRT_F32;
@@ -227,7 +261,11 @@ template <typename T> struct Impl : CtxBase {
         for (int k = 0; k < 16; k++)
             sc.cam_L2W.m[k] = (T)camera.transform_L2W[k];
         sc.cam_fovy = (T)camera.field_of_view_y;
-        sc.sky_valid = 0;
+        sc.sky_valid = skybox.valid ? 1u : 0u;
+        sc.sky_texture = skybox.texture;
+        sc.sky_dx = (T)skybox.delta_x;
+        sc.sky_dy = (T)skybox.delta_y;
+        sc.sky_exposure = (T)skybox.exposure;
         const uint32_t total_px = win.W * win.H, first_px = win.row_begin * win.W, npix = win.npix();
         auto seed_of = [&](uint32_t s, int which) -> uint64_t {
             if (fs.seeds)
@@ -357,6 +395,10 @@ template <typename T> struct Impl : CtxBase {
         geo.upload(stream, vbo, nv, ebo, ni, vaos, nvaos);
     }
     void upload_materials(const lprt_material *m, uint32_t n) override {
+        for (uint32_t i = 0; i < n; i++)
+            if (m[i].uv_color < 2u && m[i].tex_color >= tex.host.size())
+                throw std::string("material ") + std::to_string(i) + " names texture handle " + std::to_string(m[i].tex_color) +
+                    " which lprt_upload_texture has not returned (upload textures before materials)";
         n_materials = n;
         d_materials32.reserve(sizeof(lprt_material) * (size_t)std::max(n, 1u));
         d_materials.reserve(sizeof(MaterialT<T>) * (size_t)std::max(n, 1u));
@@ -396,10 +438,13 @@ template <typename T> struct Impl : CtxBase {
         launch_convert_lights<T>(stream, d_lights32.as<lprt_light>(), d_lights.as<LightT<T>>(), nl);
         camera = *cam;
         std::memcpy(w2c, W2C, sizeof(w2c));
-        if (sky)
+        if (sky && sky->valid) {
+            if (sky->texture >= tex.host.size())
+                throw std::string("skybox names a texture handle lprt_upload_texture has not returned");
             skybox = *sky;
-        else
+        } else {
             skybox = lprt_skybox{};
+        }
         have_scene = true;
         objrecs_dirty = true;
     }
@@ -430,7 +475,8 @@ template <typename T> struct Impl : CtxBase {
         sc.vaos = geo.d_vaos.template as<lprt_mesh_vao>();
         sc.materials = d_materials.template as<MaterialT<T>>();
         sc.lights = d_lights.template as<LightT<T>>();
-        sc.textures = nullptr;
+        sc.textures = tex.table.template as<Texture>();
+        sc.srgb_lut = tex.lut.template as<float>();
         sc.n_lights = n_lights;
         sc.n_vaos = geo.n_vaos;
         sc.lim_vertices = geo.n_vertices;
@@ -703,8 +749,32 @@ int lprt_upload_materials(lprt_ctx *ctx, const lprt_material *materials, uint32_
         c.upload_materials(materials, n);
     });
 }
-int lprt_upload_texture(lprt_ctx *ctx, const uint8_t *, uint32_t, uint32_t, uint32_t, uint32_t *) {
-    return guarded(ctx, [&](CtxBase &) { throw std::string("textures are not implemented yet (SURVEY.md §8(f) rank 2)"); });
+int lprt_upload_texture(lprt_ctx *ctx, const uint8_t *rgba8, uint32_t width, uint32_t height, uint32_t srgb, uint32_t *handle) {
+    return guarded(ctx, [&](CtxBase &c) {
+        if (!rgba8 || !handle)
+            throw std::string("null texture pointer");
+        if (!width || !height || width > 32768u || height > 32768u)
+            throw std::string("texture extent must be 1..32768");
+        *handle = c.tex.add(c.stream, rgba8, width, height, srgb != 0);
+    });
+}
+int lprt_debug_sample_texture(lprt_ctx *ctx, uint32_t handle, const float *uv, uint32_t n, float *rgba) {
+    return guarded(ctx, [&](CtxBase &c) {
+        if (handle >= c.tex.host.size())
+            throw std::string("unknown texture handle");
+        if (n && (!uv || !rgba))
+            throw std::string("null uv/rgba pointer");
+        if (!n)
+            return;
+        DevBuf d_uv, d_out;
+        d_uv.reserve(sizeof(float) * 2 * (size_t)n);
+        d_out.reserve(sizeof(float) * 4 * (size_t)n);
+        LPRT_HIP(hipMemcpyAsync(d_uv.ptr, uv, sizeof(float) * 2 * (size_t)n, hipMemcpyHostToDevice, c.stream));
+        launch_sample_texture(c.stream, c.tex.table.as<Texture>(), c.tex.lut.as<float>(), handle, d_uv.as<float>(), n, d_out.as<float>());
+        LPRT_HIP(hipGetLastError());
+        LPRT_HIP(hipMemcpyAsync(rgba, d_out.ptr, sizeof(float) * 4 * (size_t)n, hipMemcpyDeviceToHost, c.stream));
+        LPRT_HIP(hipStreamSynchronize(c.stream));
+    });
 }
 int lprt_build_blas(lprt_ctx *ctx) {
     return guarded(ctx, [&](CtxBase &c) { c.build_blas(); });

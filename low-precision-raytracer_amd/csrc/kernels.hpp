@@ -14,6 +14,7 @@ template <typename T> void launch_convert_objects(hipStream_t st, const lprt_obj
 template <typename T> void launch_convert_materials(hipStream_t st, const lprt_material *in, MaterialT<T> *out, uint32_t n);
 template <typename T> void launch_convert_lights(hipStream_t st, const lprt_light *in, LightT<T> *out, uint32_t n);
 template <typename T> void launch_convert_mat4(hipStream_t st, const float *in, M4<T> *out, uint32_t n);
+void launch_sample_texture(hipStream_t st, const Texture *textures, const float *lut, uint32_t handle, const float *uv, uint32_t n, float *rgba);
 
 
 // pipeline.hip

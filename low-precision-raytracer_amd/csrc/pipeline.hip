@@ -199,15 +199,18 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev<T> sc, FrameDev<T> fb, u
     V3<T> position, raw_normal, raw_tangent, vertex_color;
     MaterialT<T> material;
     uint32_t inscene_objid, inobject_offset, objectid;
-    bool live = true;
+    V4<T> uv4 = zero4;
+    bool live = true, sky_pixel = false;
     if (FIRST) {
         const uint32_t c4 = fb.g_color[p];
         // to_color_float (cuda.hpp:890-892): DataT(c / 255.f)
         vertex_color = mk3(cvt<T>((float)(c4 & 255u) / 255.f), cvt<T>((float)((c4 >> 8) & 255u) / 255.f),
                            cvt<T>((float)((c4 >> 16) & 255u) / 255.f));
         if ((c4 >> 24) == 0) {
-            live = false; // empty pixel (cuda.hpp:1781-1796); skybox is handled in compose when valid
+            live = false; // empty pixel (cuda.hpp:1781-1796)
+            sky_pixel = true;
         } else {
+            uv4 = fb.g_uv[p];
             inscene_objid = fb.g_objid[p];
             inobject_offset = fb.g_offset[p];
             position = xyz(fb.g_position[p]);
@@ -218,9 +221,12 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev<T> sc, FrameDev<T> fb, u
             objectid = oc->objectid;
         }
     } else {
-        if (fb.sc_type[p] != 1u) { // INVALID or SKYBOX (cuda.hpp:1819-1833); Q5: invalid skybox contributes 0
+        const uint32_t type = fb.sc_type[p];
+        if (type != 1u) { // INVALID or SKYBOX (cuda.hpp:1819-1833); Q5: invalid skybox contributes 0
             live = false;
+            sky_pixel = type == 2u;
         } else {
+            uv4 = fb.sc_uv[p];
             vertex_color = xyz(fb.sc_color[p]);
             inscene_objid = fb.sc_objid[p];
             inobject_offset = fb.sc_offset[p];
@@ -233,7 +239,12 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev<T> sc, FrameDev<T> fb, u
     }
     V3<T> color, normal, view_dir;
     if (live) {
-        color = ld3(material.color); // uv_color >= 2: no texture fetch (cuda.hpp:1850-1855)
+        color = ld3(material.color);
+        if (material.uv_color < 2u) { // cuda.hpp:1850-1855
+            const float4 tc = material.uv_color == 0u ? tex2d(sc.textures, sc.srgb_lut, material.tex_color, (float)uv4.x, (float)uv4.y)
+                                                      : tex2d(sc.textures, sc.srgb_lut, material.tex_color, (float)uv4.z, (float)uv4.w);
+            color = mk3(cvt<T>(tc.x), cvt<T>(tc.y), cvt<T>(tc.z));
+        }
         color = elemul(color, vertex_color);
         normal = raw_normal;
         if (FIRST)
@@ -382,6 +393,12 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev<T> sc, FrameDev<T> fb, u
                 fb.lc_multiplier[i * npix + p] = mk4(mm.x, mm.y, mm.z, zero);
             }
         }
+    }
+    if (sky_pixel && sc.sky_valid) {
+        // the reference parks this in di_intensity[4p + 0]; accumulate_di_light then adds 0 + sky + 0 + 0 + 0 to a cleared pixel
+        V3<T> dir = FIRST ? primary_ray_direction(sc, fb.win.W, fb.win.H, x, y) : neg(normalized(xyz(fb.view_direction[p])));
+        V3<T> sky = sample_skybox(sc, dir);
+        o_intensity = mk4(sky.x, sky.y, sky.z, zero);
     }
     fb.lc_mask[p] = (uint8_t)mask;
     intensity[p] = o_intensity;

@@ -138,4 +138,50 @@ template <typename T> LPRT_DEV V3<T> primary_ray_direction(const SceneDev<T> &sc
     return normalized(xform_dir(sc.cam_L2W, mk3(x, y, (T)(-1))));
 }
 
+
+// ---- textures: RDTexture (memory.hpp:334-369) as the texture unit is documented to fetch it -------------------------
+// normalised coordinates, wrap addressing (the reference leaves addressMode at 0), linear filter at xB = x - 0.5 with
+// 1.8 fixed-point blend weights, 8-bit texels read as c/255 or through the sRGB table (alpha is never decoded).
+LPRT_DEV void tex_wrap(float u, uint32_t n, int &i0, int &i1, float &alpha) {
+    float f = u - ::floorf(u);
+    if (!(f == f) || !(f < 1.f)) // NaN / inf coordinate: texel 0
+        f = 0.f;
+    const float xb = f * (float)n - 0.5f;
+    const float fl = ::floorf(xb);
+    alpha = ::rintf((xb - fl) * 256.f) * (1.f / 256.f);
+    i0 = (int)fl;
+    i1 = i0 + 1;
+    if (i0 < 0)
+        i0 += (int)n;
+    if (i1 >= (int)n)
+        i1 -= (int)n;
+}
+LPRT_DEV float4 tex_texel(const Texture &t, const float *lut, int i, int j) {
+    const uint32_t c = t.texels[(size_t)j * t.width + (size_t)i];
+    const uint32_t r = c & 255u, g = (c >> 8) & 255u, b = (c >> 16) & 255u, a = c >> 24;
+    if (t.srgb)
+        return make_float4(lut[r], lut[g], lut[b], (float)a / 255.f);
+    return make_float4((float)r / 255.f, (float)g / 255.f, (float)b / 255.f, (float)a / 255.f);
+}
+LPRT_DEV float4 tex2d(const Texture *textures, const float *lut, uint32_t handle, float u, float v) {
+    const Texture t = textures[handle];
+    int i0, i1, j0, j1;
+    float a, b;
+    tex_wrap(u, t.width, i0, i1, a);
+    tex_wrap(v, t.height, j0, j1, b);
+    const float4 t00 = tex_texel(t, lut, i0, j0), t10 = tex_texel(t, lut, i1, j0), t01 = tex_texel(t, lut, i0, j1), t11 = tex_texel(t, lut, i1, j1);
+    const float w00 = (1.f - a) * (1.f - b), w10 = a * (1.f - b), w01 = (1.f - a) * b, w11 = a * b;
+    return make_float4(w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x, w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y,
+                       w00 * t00.z + w10 * t10.z + w01 * t01.z + w11 * t11.z, w00 * t00.w + w10 * t10.w + w01 * t01.w + w11 * t11.w);
+}
+// direction_to_spherical (cuda.hpp:1742-1749) + the skybox fetch of shade() (cuda.hpp:1786-1791, 1828-1832)
+template <typename T> LPRT_DEV V3<T> sample_skybox(const SceneDev<T> &sc, const V3<T> &dir) {
+    float u = 0.1591f * ::atan2f((float)dir.y, (float)dir.x) + 0.5f + (float)sc.sky_dx;
+    float v = 0.3183f * ::asinf((float)dir.z) + 0.5f + (float)sc.sky_dy;
+    u = ::fmodf(u, 1.f);
+    v = 1.f - ::fmodf(v, 1.f);
+    const float4 c = tex2d(sc.textures, sc.srgb_lut, sc.sky_texture, u, v);
+    return mk3(cvt<T>(c.x), cvt<T>(c.y), cvt<T>(c.z)) * sc.sky_exposure;
+}
+
 } // namespace lprt

@@ -1,6 +1,7 @@
 // Ray-casting kernels: host ray batches (lprt_trace_rays), primary rays -> G-buffer (G1, G2),
 // GI rays (TG) and shadow rays (TD).
 #include "kernels.hpp"
+#include "shade.hpp"
 #include "trace.hpp"
 
 namespace lprt {
@@ -160,6 +161,21 @@ template <typename T> void launch_convert_mat4(hipStream_t st, const float *in, 
     if (n)
         hipLaunchKernelGGL(k_convert_mat4<T>, dim3((n * 16 + 63) / 64), dim3(64), 0, st, in, out, n);
 }
+// test hook behind lprt_debug_sample_texture: the same fetch shade() makes
+__global__ void k_sample_texture(const Texture *textures, const float *lut, uint32_t handle, const float *uv, uint32_t n, float *rgba) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const float4 c = tex2d(textures, lut, handle, uv[2 * i], uv[2 * i + 1]);
+    rgba[4 * i + 0] = c.x;
+    rgba[4 * i + 1] = c.y;
+    rgba[4 * i + 2] = c.z;
+    rgba[4 * i + 3] = c.w;
+}
+void launch_sample_texture(hipStream_t st, const Texture *textures, const float *lut, uint32_t handle, const float *uv, uint32_t n, float *rgba) {
+    hipLaunchKernelGGL(k_sample_texture, dim3((n + 255) / 256), dim3(256), 0, st, textures, lut, handle, uv, n, rgba);
+}
+
 #define INST(T)                                                                                                        \
     template void launch_make_objrecs<T>(hipStream_t, const ObjSlot<T> *, const ObjConst<T> *, const BlasInfo *, const T *, uint32_t, uint32_t,    \
                                          ObjRec<T> *);                                                                 \

@@ -104,6 +104,7 @@ template <typename T> struct SceneDev {
     const MaterialT<T> *materials;
     const LightT<T> *lights;
     const Texture *textures;
+    const float *srgb_lut; // 256 entries: 8-bit sRGB -> linear
     uint32_t n_lights, n_vaos;
     // camera (RDCamera<DataT>, memory.hpp:382-405)
     M4<T> cam_L2W;

@@ -13,7 +13,7 @@ load_material, :544-690 build_object_hierarchy, :737-828 load_gltf2) and of hier
   * first perspective camera found depth-first (hierarchy.hpp:203-214).
 
 Supported: .gltf (external .bin or data: URIs) and .glb; float/u8/u16/u32 accessors with byteStride; TRIANGLES only;
-base-colour textures (PNG/JPEG through Pillow) are returned as RGBA8 arrays in `SceneData.meta["textures"]`.
+base-colour textures (PNG/JPEG through Pillow) are returned as RGBA8 arrays in `SceneData.textures`.
 `save_gltf` writes a SceneData back as .gltf + .bin with one bufferView per accessor (the reference's load_data takes
 its element count from bufferView.byteLength / stride).
 """
@@ -225,8 +225,9 @@ def load_gltf(path, width_over_height=16 / 9):
     fwd = (cam_m @ np.array([0, 0, -1, 0.0]))[:3]
     meshes = [p[0] for p in prims]
     sc = scenes.assemble(os.path.splitext(os.path.basename(path))[0], meshes, materials, instances, lights, cam_eye=tuple(eye),
-                         cam_target=tuple(eye + fwd), fovy=float(persp["yfov"]), meta=dict(textures=textures, source=path))
+                         cam_target=tuple(eye + fwd), fovy=float(persp["yfov"]), meta=dict(source=path))
     sc.z_near, sc.z_far = float(persp.get("znear", 0.1)), float(persp.get("zfar", 100.0))
+    sc.textures = textures
     # attributes assemble() does not synthesise
     vo = 0
     for mesh_obj, _, extra in prims:

@@ -46,6 +46,7 @@ SYMBOLS = [
     ("lprt_get_stage_counters", C.c_int, [_P, C.c_int, _P]),
     ("lprt_reset_counters", C.c_int, [_P]),
     ("lprt_set_output_target", C.c_int, [_P, _P, C.c_uint32, C.c_uint32]),
+    ("lprt_debug_sample_texture", C.c_int, [_P, C.c_uint32, _P, C.c_uint32, _P]),
     ("lprt_debug_rng_states", C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_uint32, _P]),
     ("lprt_enable_stage_timing", C.c_int, [_P, C.c_int]),
     ("lprt_get_stage_times", C.c_int, [_P, _P, _P]),
@@ -127,7 +128,8 @@ class Renderer:
         vaos = sc.c_vaos()
         self._check(self.L.lprt_upload_geometry(self.h, _ptr(verts), len(verts), _ptr(idx), len(idx), C.byref(vaos),
                                                 len(vaos)), "lprt_upload_geometry")
-        mats = sc.c_materials()
+        self.tex_handles = [self.upload_texture(t["rgba8"], t.get("srgb", True)) for t in sc.textures]
+        mats = sc.c_materials(self.tex_handles)
         self._check(self.L.lprt_upload_materials(self.h, C.byref(mats), len(mats)), "lprt_upload_materials")
         if build:
             self.build_blas()
@@ -135,14 +137,31 @@ class Renderer:
     def build_blas(self):
         self._check(self.L.lprt_build_blas(self.h), "lprt_build_blas")
 
+    def upload_texture(self, rgba8, srgb=True):
+        """RDTexture(data, w, h, sRGB) (rt/rtrt/memory.hpp:334-369); returns the handle materials / the skybox name."""
+        img = np.ascontiguousarray(rgba8, dtype=np.uint8)
+        assert img.ndim == 3 and img.shape[2] == 4
+        handle = C.c_uint32()
+        self._check(self.L.lprt_upload_texture(self.h, _ptr(img), img.shape[1], img.shape[0], int(bool(srgb)), C.byref(handle)),
+                    "lprt_upload_texture")
+        return handle.value
+
+    def sample_texture(self, handle, uv):
+        """Device texture fetches at normalised coordinates uv[n, 2] -> float32 [n, 4] (test hook)."""
+        uv = np.ascontiguousarray(uv, dtype=np.float32)
+        out = np.zeros((len(uv), 4), dtype=np.float32)
+        self._check(self.L.lprt_debug_sample_texture(self.h, handle, _ptr(uv), len(uv), _ptr(out)), "lprt_debug_sample_texture")
+        return out
+
     # ---- scene-manager side: the RDScene of this frame ------------------------------------------------
     def set_scene(self, sc=None):
         sc = sc or self.scene
         objs, aabbs, lights = sc.c_objects(), sc.c_aabbs(), sc.c_lights()
         cam = sc.c_camera(self.W, self.H)
         w2c = np.ascontiguousarray(sc.transform_W2C(self.W, self.H), dtype=np.float32)
+        sky = sc.c_skybox(getattr(self, "tex_handles", None))
         self._check(self.L.lprt_set_scene(self.h, C.byref(objs), C.byref(aabbs), len(sc.objects), C.byref(lights),
-                                          len(sc.lights), C.byref(cam), _ptr(w2c), None), "lprt_set_scene")
+                                          len(sc.lights), C.byref(cam), _ptr(w2c), C.byref(sky) if sky else None), "lprt_set_scene")
 
     def load_scene(self, sc):
         self.set_rdresource(sc)

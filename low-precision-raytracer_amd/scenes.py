@@ -85,6 +85,7 @@ class Mesh:
     indices: np.ndarray
     uv0: np.ndarray = None
     colors: np.ndarray = None
+    uv1: np.ndarray = None
 
     @property
     def n_tris(self):
@@ -108,6 +109,8 @@ class SceneData:
     z_far: float = 100.0
     local_aabbs: np.ndarray = None
     meta: dict = field(default_factory=dict)
+    textures: list = field(default_factory=list)   # dict(rgba8=uint8[h, w, 4], srgb=bool); materials name them by "tex_index"
+    skybox: dict = None                             # dict(tex_index, delta_x, delta_y, exposure) or None
 
     @property
     def n_tris(self):
@@ -124,7 +127,8 @@ class SceneData:
             arr[i] = abi.MeshVAO(int(v[0]), int(v[1]), int(v[2]), int(v[3]))
         return arr
 
-    def c_materials(self):
+    def c_materials(self, tex_handles=None):
+        """tex_handles[i] = the handle lprt_upload_texture returned for self.textures[i]."""
         arr = (abi.Material * len(self.materials))()
         for i, m in enumerate(self.materials):
             c = arr[i]
@@ -135,7 +139,17 @@ class SceneData:
             c.double_sided = int(m.get("double_sided", True))
             c.uv_color = int(m.get("uv_color", 0xFFFFFFFF))
             c.tex_color = int(m.get("tex_color", 0))
+            if "tex_index" in m and c.uv_color < 2:
+                k = int(m["tex_index"])  # an index nobody uploaded is passed through for the library to reject
+                c.tex_color = int(tex_handles[k]) if tex_handles is not None and k < len(tex_handles) else k
         return arr
+
+    def c_skybox(self, tex_handles=None):
+        if not self.skybox:
+            return None
+        k = self.skybox["tex_index"]
+        return abi.Skybox(1, int(tex_handles[k]) if tex_handles is not None else int(k), float(self.skybox.get("delta_x", 0.0)),
+                          float(self.skybox.get("delta_y", 0.0)), float(self.skybox.get("exposure", 1.0)))
 
     def c_objects(self):
         arr = (abi.Object * len(self.objects))()
@@ -195,6 +209,8 @@ def assemble(name, meshes, materials, instances, lights, cam_eye, cam_target, fo
         verts["color"][vo:vo + n] = 1.0 if m.colors is None else np.asarray(m.colors, dtype=np.float32)
         if m.uv0 is not None:
             verts["uv0"][vo:vo + n] = np.asarray(m.uv0, dtype=np.float32)
+        if m.uv1 is not None:
+            verts["uv1"][vo:vo + n] = np.asarray(m.uv1, dtype=np.float32)
         idx = np.asarray(m.indices, dtype=np.uint32)
         assert len(idx) % 3 == 0 and idx.max() < n
         idx_parts.append(idx + np.uint32(vo))
@@ -489,4 +505,46 @@ def small_test_scene(seed=7, n_tris_per_object=40, n_objects=5):
                     fovy=0.8)
 
 
-SCENES = {"cornell": cornell_box, "sponza_like": sponza_like, "small_test": small_test_scene}
+def checker_texture(w=16, h=8, seed=3):
+    """Small RGBA8 image with distinct texels everywhere (a checker modulated by a seeded random tint)."""
+    rng = np.random.default_rng(seed)
+    img = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    dark = ((xx + yy) & 1) == 0
+    img[dark, :3] //= 4
+    img[..., 3] = 255
+    return img
+
+
+def textured_scene():
+    """Open scene for the texture / skybox paths: a floor whose uv0 runs 0..3 (wrap addressing) with an sRGB
+    base-colour texture, a box textured through uv1 with a linear texture, an untextured box, and an
+    equirectangular sky texture behind everything (most of the frame is empty pixels)."""
+    floor = quad_grid((-2, -1, 2), (4, 0, 0), (0, 0, -4), 4, 4)
+    floor.uv0 = floor.uv0 * 3.0 - 0.75
+    box = unit_cube()
+    box.uv1 = box.uv0 * 1.5
+    box.uv0 = None
+    plain = unit_cube()
+    materials = [dict(color=(0.8, 0.8, 0.8), metallic=0.0, roughness=1.0),
+                 dict(color=(0.2, 0.9, 0.2), metallic=0.0, roughness=0.8, uv_color=0, tex_index=0),   # colour factor unused once textured
+                 dict(color=(1.0, 1.0, 1.0), metallic=0.5, roughness=0.4, uv_color=1, tex_index=1),
+                 dict(color=(0.7, 0.3, 0.2), metallic=0.0, roughness=0.05)]
+    instances = [(0, 1, np.eye(4)), (1, 2, translate((-0.6, -0.5, 0.0)) @ rotate_y(25.0)),
+                 (2, 3, translate((0.7, -0.6, 0.4)) @ rotate_y(-15.0) @ scale((0.8, 0.8, 0.8)))]
+    lights = [dict(type=abi.LIGHT_POINT, position=(0.5, 2.5, 1.5), intensity=(40.0, 38.0, 35.0)),
+              dict(type=abi.LIGHT_DIRECTIONAL, direction=(-0.4, -1.0, -0.3), intensity=(1.2, 1.2, 1.3))]
+    sc = assemble("textured", [floor, box, plain], materials, instances, lights, cam_eye=(0.2, 0.6, 4.5), cam_target=(0, -0.3, 0), fovy=0.8)
+    sky = np.zeros((32, 64, 4), dtype=np.uint8)
+    yy, xx = np.mgrid[0:32, 0:64]
+    sky[..., 0] = 40 + 3 * xx
+    sky[..., 1] = 90 + 5 * yy
+    sky[..., 2] = 255 - 2 * xx
+    sky[..., 3] = 255
+    sc.textures = [dict(rgba8=checker_texture(16, 8, 3), srgb=True), dict(rgba8=checker_texture(5, 7, 11), srgb=False),
+                   dict(rgba8=sky, srgb=True)]
+    sc.skybox = dict(tex_index=2, delta_x=0.125, delta_y=0.0, exposure=1.5)
+    return sc
+
+
+SCENES = {"textured": textured_scene, "cornell": cornell_box, "sponza_like": sponza_like, "small_test": small_test_scene}

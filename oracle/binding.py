@@ -40,6 +40,8 @@ def lib():
         L.orc_set_scene.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
                                     C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_render_frame.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_upload_texture.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+        L.orc_tex2d.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
         L.orc_reset_history.argtypes = [C.c_void_p]
         L.orc_read_buffer.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         L.orc_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
@@ -113,16 +115,30 @@ class Oracle:
         vaos = sc.c_vaos()
         rc = self.L.orc_upload_geometry(self.h, _ptr(verts), len(verts), _ptr(idx), len(idx), C.byref(vaos), len(vaos))
         assert rc == 0, rc
-        mats = sc.c_materials()
+        self.tex_handles = [self.upload_texture(t["rgba8"], t.get("srgb", True)) for t in sc.textures]
+        mats = sc.c_materials(self.tex_handles)
         assert self.L.orc_upload_materials(self.h, C.byref(mats), len(mats)) == 0
         self.set_scene(sc)
+
+    def upload_texture(self, rgba8, srgb=True):
+        img = np.ascontiguousarray(rgba8, dtype=np.uint8)
+        handle = C.c_uint32()
+        assert self.L.orc_upload_texture(self.h, _ptr(img), img.shape[1], img.shape[0], int(bool(srgb)), C.byref(handle)) == 0
+        return handle.value
+
+    def sample_texture(self, handle, uv):
+        uv = np.ascontiguousarray(uv, dtype=np.float32)
+        out = np.zeros((len(uv), 4), dtype=np.float32)
+        assert self.L.orc_tex2d(self.h, handle, _ptr(uv), len(uv), _ptr(out)) == 0
+        return out
 
     def set_scene(self, sc):
         objs, aabbs, lights = sc.c_objects(), sc.c_aabbs(), sc.c_lights()
         cam = sc.c_camera(self.W, self.H)
         w2c = np.ascontiguousarray(sc.transform_W2C(self.W, self.H), dtype=np.float32)
+        sky = sc.c_skybox(getattr(self, "tex_handles", None))
         rc = self.L.orc_set_scene(self.h, C.byref(objs), C.byref(aabbs), len(sc.objects), C.byref(lights),
-                                  len(sc.lights), C.byref(cam), _ptr(w2c), None)
+                                  len(sc.lights), C.byref(cam), _ptr(w2c), C.byref(sky) if sky else None)
         assert rc == 0
 
     def render_frame(self, settings):

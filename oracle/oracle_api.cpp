@@ -131,9 +131,26 @@ int orc_upload_materials(void *p, const lprt_material *m, uint32_t n) {
     return 0;
 }
 int orc_set_scene(void *p, const lprt_object *obj, const lprt_aabb *aabbs, uint32_t n, const lprt_light *lights, uint32_t nl,
-                  const lprt_camera *cam, const float *w2c, const lprt_skybox *) {
+                  const lprt_camera *cam, const float *w2c, const lprt_skybox *sky) {
     auto *h = static_cast<Handle *>(p);
     if (h->f32) h->f32->set_scene(obj, aabbs, n, lights, nl, cam, w2c); else h->f16->set_scene(obj, aabbs, n, lights, nl, cam, w2c);
+    if (h->f32) h->f32->set_skybox(sky); else h->f16->set_skybox(sky);
+    return 0;
+}
+int orc_upload_texture(void *p, const uint8_t *rgba8, uint32_t w, uint32_t hgt, uint32_t srgb, uint32_t *handle) {
+    auto *h = static_cast<Handle *>(p);
+    if (!rgba8 || !w || !hgt || !handle)
+        return LPRT_ERR_INVALID;
+    *handle = h->f32 ? h->f32->upload_texture(rgba8, w, hgt, srgb != 0) : h->f16->upload_texture(rgba8, w, hgt, srgb != 0);
+    return 0;
+}
+int orc_tex2d(void *p, uint32_t handle, const float *uv, uint32_t n, float *rgba) {
+    auto *h = static_cast<Handle *>(p);
+    for (uint32_t i = 0; i < n; i++) {
+        auto c = h->f32 ? h->f32->tex2d(handle, uv[2 * i], uv[2 * i + 1]) : h->f16->tex2d(handle, uv[2 * i], uv[2 * i + 1]);
+        for (int k = 0; k < 4; k++)
+            rgba[4 * i + k] = c[k];
+    }
     return 0;
 }
 int orc_render_frame(void *p, const lprt_frame_settings *fs) {

@@ -31,7 +31,14 @@ template <typename T> struct Material {
     Vec3<T> color, emission;
     T metallic, roughness;
     bool double_sided;
-    uint32_t uv_color;
+    uint32_t uv_color, tex_color;
+};
+// RDTexture (memory.hpp:334-369): RGBA8 pitch2D, cudaReadModeNormalizedFloat, cudaFilterModeLinear, normalised
+// coordinates, address mode left at 0 = wrap, optional sRGB decode.
+struct TextureData {
+    std::vector<uint8_t> rgba;
+    uint32_t width = 0, height = 0;
+    bool srgb = false;
 };
 template <typename T> struct ObjectConstant {
     Mat4<T> transform_L2W, transform_W2L;
@@ -286,6 +293,7 @@ template <typename T> class Renderer {
     double stage_seconds[LPRT_STAGE_COUNT] = {};
 
     Renderer(uint32_t w, uint32_t h) : W(w), H(h) {
+        init_srgb_lut();
         size_t n = size_t(w) * h;
         g_position.assign(n, Vec4<T>());
         g_normal_depth.assign(n, Vec4<T>());
@@ -382,7 +390,84 @@ template <typename T> class Renderer {
             materials[i].roughness = T(m[i].roughness);
             materials[i].double_sided = m[i].double_sided != 0;
             materials[i].uv_color = m[i].uv_color;
+            materials[i].tex_color = m[i].tex_color;
         }
+    }
+    // ---- textures: the documented behaviour of the texture unit the reference samples through ----------------
+    // (CUDA C Programming Guide, "Texture Fetching": wrap -> frac(u)*N, linear filtering at xB = x - 0.5 with the
+    // blend weights held in 1.8 fixed point; sRGB textures are decoded per texel before filtering, alpha is not.)
+    // PARITY UNPINNED: no reference image to pin the hardware's sRGB table or weight rounding against.
+    std::vector<TextureData> textures;
+    float srgb_lut[256];
+    void init_srgb_lut() {
+        for (int i = 0; i < 256; i++) {
+            double c = i / 255.0;
+            srgb_lut[i] = float(c <= 0.04045 ? c / 12.92 : std::pow((c + 0.055) / 1.055, 2.4));
+        }
+    }
+    uint32_t upload_texture(const uint8_t *rgba8, uint32_t w, uint32_t h, bool srgb) {
+        TextureData t;
+        t.rgba.assign(rgba8, rgba8 + size_t(w) * h * 4);
+        t.width = w;
+        t.height = h;
+        t.srgb = srgb;
+        textures.push_back(std::move(t));
+        return uint32_t(textures.size() - 1);
+    }
+    std::array<float, 4> texel(const TextureData &t, int i, int j) const {
+        const uint8_t *p = &t.rgba[(size_t(j) * t.width + size_t(i)) * 4];
+        if (t.srgb)
+            return {srgb_lut[p[0]], srgb_lut[p[1]], srgb_lut[p[2]], p[3] / 255.f};
+        return {p[0] / 255.f, p[1] / 255.f, p[2] / 255.f, p[3] / 255.f};
+    }
+    static void wrap_coord(float u, uint32_t n, int &i0, int &i1, float &alpha) {
+        float f = u - std::floor(u);
+        if (!(f == f) || !(f < 1.f)) // NaN / inf coordinates sample texel 0 (defined here; undefined in the reference)
+            f = 0.f;
+        float xb = f * float(n) - 0.5f;
+        float fl = std::floor(xb);
+        alpha = std::nearbyint((xb - fl) * 256.f) * (1.f / 256.f);
+        i0 = int(fl);
+        i1 = i0 + 1;
+        if (i0 < 0)
+            i0 += int(n);
+        if (i1 >= int(n))
+            i1 -= int(n);
+    }
+    std::array<float, 4> tex2d(uint32_t handle, float u, float v) const {
+        if (handle >= textures.size())
+            return {0.f, 0.f, 0.f, 0.f};
+        const TextureData &t = textures[handle];
+        int i0, i1, j0, j1;
+        float a, b;
+        wrap_coord(u, t.width, i0, i1, a);
+        wrap_coord(v, t.height, j0, j1, b);
+        auto t00 = texel(t, i0, j0), t10 = texel(t, i1, j0), t01 = texel(t, i0, j1), t11 = texel(t, i1, j1);
+        std::array<float, 4> o;
+        for (int k = 0; k < 4; k++)
+            o[k] = (1.f - a) * (1.f - b) * t00[k] + a * (1.f - b) * t10[k] + (1.f - a) * b * t01[k] + a * b * t11[k];
+        return o;
+    }
+    // RDSkybox<DataT>::Ref (memory.hpp:671-690) and direction_to_spherical (cuda.hpp:1742-1749)
+    bool sky_valid = false;
+    uint32_t sky_texture = 0;
+    T sky_dx = T(0.f), sky_dy = T(0.f), sky_exposure = T(1.f);
+    void set_skybox(const lprt_skybox *s) {
+        sky_valid = s && s->valid && s->texture < textures.size();
+        if (sky_valid) {
+            sky_texture = s->texture;
+            sky_dx = T(s->delta_x);
+            sky_dy = T(s->delta_y);
+            sky_exposure = T(s->exposure);
+        }
+    }
+    Vec3<T> sample_skybox(const Vec3<T> &dir) const {
+        float u = 0.1591f * std::atan2(float(dir[1]), float(dir[0])) + 0.5f + float(sky_dx);
+        float v = 0.3183f * std::asin(float(dir[2])) + 0.5f + float(sky_dy);
+        u = std::fmod(u, 1.f);
+        v = 1.f - std::fmod(v, 1.f);
+        auto c = tex2d(sky_texture, u, v);
+        return mk3(T(c[0]), T(c[1]), T(c[2])) * sky_exposure;
     }
 
     // ------------------------------------------------------------------------------------------
@@ -1059,7 +1144,8 @@ template <typename T> class Renderer {
             if (c4[3] == 0) {
                 for (int i = 0; i < 4; i++)
                     lc[i].slot = UINT8_MAX;
-                // skybox.valid == false in every supported scene: nothing else (cuda.hpp:1786-1794)
+                if (sky_valid) // cuda.hpp:1786-1794
+                    di_intensity[tid * 4 + 0] = sample_skybox(get_primary_ray_direction(x, y));
                 gi_valid[tid] = 0; // DEVIATION Q13
                 return;
             }
@@ -1082,6 +1168,8 @@ template <typename T> class Renderer {
                 for (int i = 0; i < 4; i++)
                     lc[i].slot = UINT8_MAX;
                 // DEVIATION Q5: an invalid skybox contributes 0 (di_intensity stays cleared)
+                if (sky_valid) // cuda.hpp:1828-1832
+                    di_intensity[tid * 4 + 0] = sample_skybox(-view_direction[tid].normalized());
                 return;
             } else {
                 vertex_color = sc.color;
@@ -1096,7 +1184,12 @@ template <typename T> class Renderer {
                 objectid = objects[inscene_objid].objectid;
             }
         }
-        Vec3<T> color = material.color; // uv_color >= 2: no texture (cuda.hpp:1850-1855)
+        Vec3<T> color = material.color;
+        if (material.uv_color < 2) { // cuda.hpp:1850-1855
+            const Vec2<T> &uv = material.uv_color == 0 ? uv0 : uv1;
+            auto tc = tex2d(material.tex_color, float(uv[0]), float(uv[1]));
+            color = mk3(T(tc[0]), T(tc[1]), T(tc[2]));
+        }
         color = elemul(color, vertex_color);
         Vec3<T> normal = raw_normal;
         Vec3<T> view_dir;
