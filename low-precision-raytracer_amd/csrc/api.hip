@@ -8,6 +8,7 @@
 #include <memory>
 #include <new>
 #include <string>
+#include <vector>
 
 namespace lprt {
 
@@ -70,6 +71,31 @@ struct CtxBase {
     virtual void reset_history() = 0;
     virtual void read_buffer(lprt_buffer_id, float *, size_t) = 0;
     virtual void output_ptr(void **, size_t *) = 0;
+    struct HistPlane {
+        void *ptr;
+        size_t bytes_per_pixel;
+    };
+    virtual std::vector<HistPlane> history_planes() = 0;
+    size_t history_row_bytes() {
+        size_t b = 0;
+        for (auto &pl : history_planes())
+            b += pl.bytes_per_pixel;
+        return b * win.W;
+    }
+    // rows [first_row, first_row + n_rows) of every history plane <-> one packed device buffer, plane after plane
+    void copy_history_rows(uint32_t first_row, uint32_t n_rows, void *packed, bool to_packed) {
+        if (first_row < win.row_begin || first_row + n_rows > win.row_end)
+            throw std::string("history rows must lie inside this context's row window");
+        size_t off = 0;
+        for (auto &pl : history_planes()) {
+            const size_t row = pl.bytes_per_pixel * win.W, bytes = row * n_rows;
+            char *plane = static_cast<char *>(pl.ptr) + row * (first_row - win.row_begin);
+            char *pk = static_cast<char *>(packed) + off;
+            if (bytes)
+                LPRT_HIP(hipMemcpyAsync(to_packed ? (void *)pk : (void *)plane, to_packed ? (void *)plane : (void *)pk, bytes, hipMemcpyDeviceToDevice, stream));
+            off += bytes;
+        }
+    }
     bool counters_enabled = false;
     StageTimer timer;
     uint64_t frame_index = 0;
@@ -383,6 +409,21 @@ template <typename T> struct Impl : CtxBase {
             LPRT_HIP(hipMemcpyAsync(dst, d_readback.ptr, sizeof(float) * n_floats, hipMemcpyDeviceToHost, stream));
         }
         LPRT_HIP(hipStreamSynchronize(stream));
+    }
+    // what frame n+1 reads of frame n beyond per-pixel G-buffer data: SVGF colour history (level-1 output) and moment
+    // history of both lobes, the TAA history and the frame counters
+    std::vector<HistPlane> history_planes() override {
+        ensure_frame_buffers();
+        std::vector<HistPlane> v;
+        for (int l = 0; l < 2; l++)
+            v.push_back({fb.lobe[l].cv_b, sizeof(V4<T>)});
+        for (int l = 0; l < 2; l++) {
+            v.push_back({fb.lobe[l].miu1_hist, sizeof(T)});
+            v.push_back({fb.lobe[l].miu2_hist, sizeof(T)});
+        }
+        v.push_back({fb.taa_history, sizeof(V4<T>)});
+        v.push_back({fb.prev_frame_count, 1});
+        return v;
     }
     void output_ptr(void **ptr, size_t *bytes) override {
         ensure_frame_buffers();
@@ -820,6 +861,27 @@ int lprt_set_output_target(lprt_ctx *ctx, void *dst, uint32_t first_row, uint32_
         c.ext_out = dst;
         c.ext_first_row = first_row;
         c.ext_rows = dst ? n_rows : 0;
+    });
+}
+int lprt_history_row_bytes(lprt_ctx *ctx, size_t *bytes) {
+    return guarded(ctx, [&](CtxBase &c) {
+        if (!bytes)
+            throw std::string("null out pointer");
+        *bytes = c.history_row_bytes();
+    });
+}
+int lprt_export_history_rows(lprt_ctx *ctx, uint32_t first_row, uint32_t n_rows, void *dst_device) {
+    return guarded(ctx, [&](CtxBase &c) {
+        if (n_rows && !dst_device)
+            throw std::string("null history buffer");
+        c.copy_history_rows(first_row, n_rows, dst_device, true);
+    });
+}
+int lprt_import_history_rows(lprt_ctx *ctx, uint32_t first_row, uint32_t n_rows, const void *src_device) {
+    return guarded(ctx, [&](CtxBase &c) {
+        if (n_rows && !src_device)
+            throw std::string("null history buffer");
+        c.copy_history_rows(first_row, n_rows, const_cast<void *>(src_device), false);
     });
 }
 int lprt_debug_rng_states(lprt_ctx *ctx, uint64_t seed, uint32_t first, uint32_t count, uint32_t *out) {

@@ -4,12 +4,20 @@ Every pixel is independent up to the denoiser, and the RNG is keyed by the GLOBA
 into row strips: rank r renders rows [r*H/N, (r+1)*H/N) plus a halo of HALO_ROWS on each side (the reach of the
 SVGF stencils), denoises locally, and writes only its own rows into its slot of the gathered image; one
 all-gather (RCCL over xGMI through torch.distributed, backend "nccl") completes the frame on every rank.  Scene
-data (geometry, BVH, materials) is replicated.  There is no other exchange on the data path.
+data (geometry, BVH, materials) is replicated.
+
+Across frames the temporal history (SVGF colour/moment history, TAA history, frame counters) of a rank's HALO rows
+is not right -- those rows lack part of their own filter support -- so after each frame every rank sends the owned
+rows its neighbours hold as halo and receives its halo rows from their owners (`exchange_history`, point-to-point
+over xGMI: 2 x 68 rows x 65 B/pixel, about 17 MB per rank at 1080p fp32).  With that the sharded sequence equals the
+single-GPU sequence as long as reprojection moves a pixel by no more than `halo - 68` rows per frame (a static
+camera needs none; pass a larger `halo` for fast vertical motion).
 """
 import numpy as np
 
-# a-trous reach 2*(1+2+4+8+16) = 62, + 1 (3x3 variance / gradient) + 4 (9x9 clamp) = 67 rows
-HALO_ROWS = 67
+# a-trous reach 2*(1+2+4+8+16) = 62, + 1 (3x3 variance / gradient) + 4 (9x9 clamp) = 67 rows of current-frame data,
+# + 1 for the bilinear history taps of the temporal accumulation at the outermost of those rows (frames >= 1)
+HALO_ROWS = 68
 
 
 def strip_rows(height, world_size, rank):
@@ -23,6 +31,21 @@ def window_rows(height, world_size, rank, halo=HALO_ROWS):
     """Rows [begin, end) a rank RENDERS: its strip plus the halo, clipped to the image."""
     b, e = strip_rows(height, world_size, rank)
     return max(0, b - halo), min(height, e + halo)
+
+
+def history_transfers(height, world_size, halo=HALO_ROWS):
+    """[(src_rank, dst_rank, row_begin, row_end)]: rows src OWNS that dst holds as halo, in a fixed global order."""
+    out = []
+    for dst in range(world_size):
+        wb, we = window_rows(height, world_size, dst, halo)
+        for src in range(world_size):
+            if src == dst:
+                continue
+            ob, oe = strip_rows(height, world_size, src)
+            b, e = max(wb, ob), min(we, oe)
+            if b < e:
+                out.append((src, dst, b, e))
+    return out
 
 
 def equal_strips(height, world_size):
@@ -39,13 +62,14 @@ class ShardedFrame:
     rehearsal) stages through host memory.
     """
 
-    def __init__(self, width, height, rank, world_size, device, backend="nccl"):
+    def __init__(self, width, height, rank, world_size, device, backend="nccl", halo=HALO_ROWS):
         import torch
         self.torch = torch
         self.W, self.H, self.rank, self.world = width, height, rank, world_size
-        self.device, self.backend = device, backend
+        self.device, self.backend, self.halo = device, backend, halo
         self.begin, self.end = strip_rows(height, world_size, rank)
-        self.win_begin, self.win_end = window_rows(height, world_size, rank)
+        self.win_begin, self.win_end = window_rows(height, world_size, rank, halo)
+        self._hist = None
         self.image = torch.zeros((height, width, 4), dtype=torch.float32, device=device)
         self.equal = equal_strips(height, world_size)
         self.max_rows = -(-height // world_size)
@@ -82,6 +106,48 @@ class ShardedFrame:
                 b, e = strip_rows(self.H, self.world, r)
                 self.image[b:e].copy_(self.recv[r, :e - b])
         return self.image
+
+
+    def exchange_history(self, renderer):
+        """After a frame: owned rows -> the neighbours that hold them as halo, halo rows <- their owners."""
+        import torch.distributed as dist
+        torch = self.torch
+        if self.world == 1:
+            return 0
+        if self._hist is None:
+            row_bytes = renderer.history_row_bytes()
+            plan = [t for t in history_transfers(self.H, self.world, self.halo) if self.rank in t[:2]]
+            staged = self.backend != "nccl"
+            self._hist = []
+            for src, dst, b, e in plan:
+                dev = torch.empty((e - b) * row_bytes, dtype=torch.uint8, device=self.device)
+                host = torch.empty((e - b) * row_bytes, dtype=torch.uint8) if staged and dev.is_cuda else None
+                self._hist.append((src, dst, b, e, dev, host))
+        for src, dst, b, e, dev, host in self._hist:
+            if src == self.rank:
+                renderer.export_history_rows(b, e - b, dev.data_ptr())
+        renderer.synchronize()  # the exports run on the renderer's stream, the transport on torch's
+        ops, moved = [], 0
+        for src, dst, b, e, dev, host in self._hist:
+            if src == self.rank:
+                if host is not None:
+                    host.copy_(dev)
+                ops.append(dist.P2POp(dist.isend, host if host is not None else dev, dst))
+            else:
+                ops.append(dist.P2POp(dist.irecv, host if host is not None else dev, src))
+            moved += dev.numel()
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        if self.torch.cuda.is_available() and str(self.device).startswith("cuda"):
+            torch.cuda.synchronize()
+        for src, dst, b, e, dev, host in self._hist:
+            if dst == self.rank:
+                if host is not None:
+                    dev.copy_(host)
+                    if dev.is_cuda:
+                        torch.cuda.synchronize()
+                renderer.import_history_rows(b, e - b, dev.data_ptr())
+        return moved
 
 
 def assemble_strips(strips, height, world_size):

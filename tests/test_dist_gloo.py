@@ -63,3 +63,89 @@ def test_all_gather_equal_strips():
 
 def test_all_gather_ragged_strips():
     _run(H=15, W=3)
+
+
+# ---- temporal-history halo exchange --------------------------------------------------------
+class _FakeRenderer:
+    """Stands in for lprt_export/import_history_rows on CPU: one 'plane' of ROW_BYTES bytes per image row; rows a
+    rank owns carry a value derived from (row, frame), halo rows carry garbage until imported."""
+    ROW_BYTES = 24
+
+    def __init__(self, frame):
+        self.f = frame
+        self.rows = {}
+
+    def render(self, k):
+        for r in range(self.f.win_begin, self.f.win_end):
+            owned = self.f.begin <= r < self.f.end
+            self.rows[r] = np.full(self.ROW_BYTES, (r * 7 + k) % 251 if owned else 255, dtype=np.uint8)
+
+    def history_row_bytes(self):
+        return self.ROW_BYTES
+
+    def synchronize(self):
+        pass
+
+    def export_history_rows(self, first, n, ptr):
+        import ctypes
+        buf = (ctypes.c_uint8 * (n * self.ROW_BYTES)).from_address(ptr)
+        np.frombuffer(buf, dtype=np.uint8)[:] = np.concatenate([self.rows[first + i] for i in range(n)])
+
+    def import_history_rows(self, first, n, ptr):
+        import ctypes
+        buf = (ctypes.c_uint8 * (n * self.ROW_BYTES)).from_address(ptr)
+        a = np.frombuffer(buf, dtype=np.uint8).reshape(n, self.ROW_BYTES)
+        for i in range(n):
+            self.rows[first + i] = a[i].copy()
+
+
+def _hist_worker(rank, world, port, H, halo, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    frame = dist.ShardedFrame(4, H, rank, world, torch.device("cpu"), backend="gloo", halo=halo)
+    r = _FakeRenderer(frame)
+    ok = True
+    for k in range(3):
+        r.render(k)
+        frame.exchange_history(r)
+        for row in range(frame.win_begin, frame.win_end):  # every row of the window now holds its OWNER's value
+            ok = ok and bool((r.rows[row] == (row * 7 + k) % 251).all())
+    q.put((rank, ok))
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+def _run_hist(H, world, halo):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hist_worker, args=(r, world, port, H, halo, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in got), got
+
+
+def test_history_exchange_two_ranks():
+    _run_hist(H=40, world=2, halo=6)
+
+
+def test_history_exchange_halo_spans_several_strips():
+    _run_hist(H=30, world=4, halo=11)  # strips of 7-8 rows: a halo reaches two neighbours on each side
+
+
+def test_history_transfer_plan_covers_every_halo_row_once():
+    for H, world, halo in ((1080, 8, dist.HALO_ROWS), (1080, 2, dist.HALO_ROWS), (30, 4, 11), (15, 4, 3)):
+        plan = dist.history_transfers(H, world, halo)
+        for dst in range(world):
+            wb, we = dist.window_rows(H, world, dst, halo)
+            ob, oe = dist.strip_rows(H, world, dst)
+            got = sorted(r for s, d, b, e in plan if d == dst for r in range(b, e))
+            assert got == [r for r in range(wb, we) if not ob <= r < oe]
+        for s, d, b, e in plan:
+            sb, se = dist.strip_rows(H, world, s)
+            assert sb <= b < e <= se

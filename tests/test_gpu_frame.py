@@ -148,7 +148,7 @@ def test_counters_match_oracle_ray_counts(cornell):
 
 @pytest.mark.parametrize("world", [2, 8])
 def test_row_strips_with_halo_equal_the_full_frame(cornell, world):
-    """Sharded rendering (option A): a rank's strip rendered with a 67-row halo is bit-identical to the
+    """Sharded rendering (option A): a rank's strip rendered with the 68-row halo is bit-identical to the
     same rows of the single-GPU frame (frame 0), for every rank of a 2- and an 8-way split."""
     W, H = 192, 432
     full = lprt_amd.Renderer(W, H, abi.F32)
@@ -266,3 +266,53 @@ def test_texture_errors():
         r.set_rdresource(sc)
     with pytest.raises(lprt_amd.LprtError):
         r.upload_texture(np.zeros((0, 4, 4), dtype=np.uint8))
+
+
+@pytest.mark.parametrize("prec", [abi.F32, abi.F16])
+def test_sharded_sequence_with_history_exchange_equals_single_gpu(cornell, prec):
+    """§8(f) rank 4: three frames on a 3-way row split.  With the per-frame exchange of halo-row history (what
+    dist.ShardedFrame.exchange_history does between ranks) every frame equals the single-GPU frame bit for bit;
+    without it the strips drift from frame 1 on."""
+    import torch
+    W, H, world, frames = 160, 300, 3, 3
+    full = lprt_amd.Renderer(W, H, prec)
+    full.load_scene(cornell)
+    wins = [dist.window_rows(H, world, r) for r in range(world)]
+    strips = [dist.strip_rows(H, world, r) for r in range(world)]
+
+    def make():
+        rs = []
+        for wb, we in wins:
+            r = lprt_amd.Renderer(W, H, prec, row_begin=wb, row_end=we)
+            r.load_scene(cornell)
+            rs.append(r)
+        return rs
+
+    with_x, without_x = make(), make()
+    row_bytes = with_x[0].history_row_bytes()
+    assert row_bytes == W * (65 if prec == abi.F32 else 33)
+    plan = dist.history_transfers(H, world)
+    drift = False
+    for k in range(frames):
+        fs = abi.default_settings(spp=1)
+        full.set_scene(cornell)
+        full.render(fs)
+        want = full.read("OUTPUT")
+        for rs in (with_x, without_x):
+            for r in rs:
+                r.set_scene(cornell)
+                r.render(fs)
+        for src, dst, b, e in plan:  # device-to-device here; over RCCL p2p between processes in dist.py
+            buf = torch.empty((e - b) * row_bytes, dtype=torch.uint8, device="cuda")
+            with_x[src].export_history_rows(b, e - b, buf.data_ptr())
+            with_x[src].synchronize()
+            with_x[dst].import_history_rows(b, e - b, buf.data_ptr())
+            with_x[dst].synchronize()
+        got = dist.assemble_strips([r.read("OUTPUT")[b - wb:e - wb] for r, (wb, we), (b, e) in zip(with_x, wins, strips)], H, world)
+        assert np.array_equal(got, want, equal_nan=True), f"frame {k}"  # one wall-edge pixel is NaN in the reference semantics too
+        other = dist.assemble_strips([r.read("OUTPUT")[b - wb:e - wb] for r, (wb, we), (b, e) in zip(without_x, wins, strips)], H, world)
+        drift = drift or not np.array_equal(other, want, equal_nan=True)
+    if prec == abi.F32:  # (fp16 rounding can absorb the last-bit differences of the truncated stencils)
+        assert drift, "the exchange is supposed to matter from frame 1 on"
+    with pytest.raises(lprt_amd.LprtError, match="row window"):
+        with_x[0].export_history_rows(wins[0][1], 1, 0xdead0000)
