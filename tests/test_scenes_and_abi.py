@@ -93,3 +93,16 @@ def test_strip_partition_covers_the_frame():
             assert 0 <= wb <= rows[r][0] and rows[r][1] <= we <= H
             assert rows[r][0] - wb <= dist.HALO_ROWS and we - rows[r][1] <= dist.HALO_ROWS
     assert dist.strip_rows(1080, 8, 3) == (405, 540) and dist.strip_rows(2160, 8, 7) == (1890, 2160)
+
+
+def test_image_writer_roundtrip(tmp_path):
+    from lprt_amd import image_io
+    from PIL import Image
+    a = np.random.default_rng(0).uniform(-0.2, 1.3, size=(5, 7, 4)).astype(np.float32)
+    a[0, 0, 0] = np.nan
+    image_io.save_png(str(tmp_path / "a.png"), a)
+    png = np.asarray(Image.open(str(tmp_path / "a.png")))
+    assert png.shape == (5, 7, 3) and png[4, 0, 0] == 0                      # row 0 of the frame is the bottom PNG row; NaN -> 0
+    assert png[4, 1, 1] == int(np.clip(a[0, 1, 1], 0, 1) * 255 + 0.5)
+    image_io.save_pfm(str(tmp_path / "a.pfm"), np.nan_to_num(a))
+    assert np.array_equal(image_io.load_pfm(str(tmp_path / "a.pfm")), np.nan_to_num(a)[..., :3])
