@@ -10,7 +10,9 @@ load_material, :544-690 build_object_hierarchy, :737-828 load_gltf2) and of hier
   * node TRS or matrix, T*R*S down the tree (hierarchy.hpp:145-149, 240); world AABB from the 8 transformed corners;
   * KHR_lights_punctual: intensity = colour * intensity, spot lights are loaded as POINT (loader.cu:596-619), light
     direction = normalize(L2W*(0,0,-1,0)), position = L2W[3].xyz (hierarchy.hpp:250-254);
-  * first perspective camera found depth-first (hierarchy.hpp:203-214).
+  * first perspective camera found depth-first (hierarchy.hpp:203-214);
+  * node animations (translation / rotation / scale samplers, loader.cu:692-733) are kept: `scene.pose(t)` applies
+    Object::apply_animation (hierarchy.hpp:81-143) and returns the RDScene of that instant.
 
 Supported: .gltf (external .bin or data: URIs) and .glb; float/u8/u16/u32 accessors with byteStride; TRIANGLES only;
 base-colour textures (PNG/JPEG through Pillow) are returned as RGBA8 arrays in `SceneData.textures`.
@@ -103,17 +105,109 @@ def _quat_to_mat(q):
                      [0, 0, 0, 1]], dtype=np.float64)
 
 
-def _node_matrix(node):
-    if node.get("matrix"):
-        return np.array(node["matrix"], dtype=np.float64).reshape(4, 4).T  # glTF matrices are column-major
+def _sample(track, time, default):
+    """Sampler<T>::sample(time, mod=true, default) (hierarchy.hpp:81-113): one key -> that key, no keys -> the node's
+    own value, past the last key the time wraps (fmodf), linear blend between the bracketing keys; quaternions are
+    blended component-wise WITHOUT renormalising (glm::lerp).  Stateless: the cursor is found from the time."""
+    if track is None or len(track[0]) == 0:
+        return np.asarray(default, dtype=np.float64)
+    times, values = track
+    if len(times) == 1:
+        return values[0].astype(np.float64)
+    t = np.float32(time)
+    if t >= times[-1]:
+        t = np.float32(np.fmod(t, times[-1]))
+    c = 0
+    while c + 2 < len(times) and times[c + 1] < t:
+        c += 1
+    u = np.float32((t - times[c]) / (times[c + 1] - times[c]))
+    return ((np.float32(1) - u) * values[c] + u * values[c + 1]).astype(np.float64)
+
+
+def _quat_angle_axis(q):
+    """glm::angle / glm::axis of a possibly non-unit quaternion (x, y, z, w), as Object::transform_matrix feeds them
+    to glm::rotate (hierarchy.hpp:145-149).  glm is a submodule absent from the reference checkout: restated from the
+    published 0.9.9 sources, unpinned."""
+    x, y, z, w = (float(v) for v in q)
+    if abs(w) > math.cos(0.5):
+        a = 2.0 * math.asin(min(1.0, math.sqrt(x * x + y * y + z * z)))
+        angle = 2.0 * math.pi - a if w < 0 else a
+    else:
+        angle = 2.0 * math.acos(w)
+    t = 1.0 - w * w
+    axis = np.array([0.0, 0.0, 1.0]) if t <= 0 else np.array([x, y, z]) / math.sqrt(t)
+    return angle, axis
+
+
+def _rotate(angle, axis):
+    n = np.linalg.norm(axis)
+    if n == 0:
+        return np.eye(4)
+    x, y, z = axis / n
+    c, s_ = math.cos(angle), math.sin(angle)
+    k = 1 - c
     m = np.eye(4)
-    if node.get("translation"):
-        m = m @ scenes.translate(node["translation"])
-    if node.get("rotation"):
-        m = m @ _quat_to_mat(node["rotation"])
-    if node.get("scale"):
-        m = m @ scenes.scale(node["scale"])
+    m[:3, :3] = [[c + x * x * k, x * y * k - z * s_, x * z * k + y * s_],
+                 [y * x * k + z * s_, c + y * y * k, y * z * k - x * s_],
+                 [z * x * k - y * s_, z * y * k + x * s_, c + z * z * k]]
     return m
+
+
+def _decompose(m):
+    """TRS of an affine matrix without skew (set_transform_matrix -> glm::decompose, hierarchy.hpp:151-157)."""
+    t = m[:3, 3].copy()
+    sc_ = np.linalg.norm(m[:3, :3], axis=0)
+    if np.linalg.det(m[:3, :3]) < 0:
+        sc_ = -sc_
+    r = m[:3, :3] / sc_
+    w = math.sqrt(max(0.0, 1 + r[0, 0] + r[1, 1] + r[2, 2])) / 2
+    if w > 1e-6:
+        q = np.array([(r[2, 1] - r[1, 2]) / (4 * w), (r[0, 2] - r[2, 0]) / (4 * w), (r[1, 0] - r[0, 1]) / (4 * w), w])
+    else:  # half-turn: pick the largest diagonal
+        i = int(np.argmax(np.diag(r)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        qi = math.sqrt(max(0.0, 1 + r[i, i] - r[j, j] - r[k, k])) / 2
+        q = np.zeros(4)
+        q[i], q[j], q[k], q[3] = qi, (r[j, i] + r[i, j]) / (4 * qi), (r[k, i] + r[i, k]) / (4 * qi), (r[k, j] - r[j, k]) / (4 * qi)
+    return t, q, sc_
+
+
+def _node_matrix(node, anim=None, time=None):
+    if anim is None or time is None:
+        if node.get("matrix"):
+            return np.array(node["matrix"], dtype=np.float64).reshape(4, 4).T  # glTF matrices are column-major
+        m = np.eye(4)
+        if node.get("translation"):
+            m = m @ scenes.translate(node["translation"])
+        if node.get("rotation"):
+            m = m @ _quat_to_mat(node["rotation"])
+        if node.get("scale"):
+            m = m @ scenes.scale(node["scale"])
+        return m
+    if node.get("matrix"):
+        t0, q0, s0 = _decompose(np.array(node["matrix"], dtype=np.float64).reshape(4, 4).T)
+    else:
+        t0, q0, s0 = node.get("translation", [0, 0, 0]), node.get("rotation", [0, 0, 0, 1]), node.get("scale", [1, 1, 1])
+    t = _sample(anim.get("translation"), time, t0)
+    q = _sample(anim.get("rotation"), time, q0)
+    sc_ = _sample(anim.get("scale"), time, s0)
+    return scenes.translate(t) @ _rotate(*_quat_angle_axis(q)) @ scenes.scale(sc_)
+
+
+def _load_animations(doc, bufs):
+    """load_animations (loader.cu:692-733): every channel of every animation lands on its target node; later
+    channels for the same node/path replace earlier ones; paths other than translation/rotation/scale are skipped."""
+    out = {}
+    for anim in doc.get("animations", []):
+        for ch in anim["channels"]:
+            path = ch["target"].get("path")
+            if path not in ("translation", "rotation", "scale") or "node" not in ch["target"]:
+                continue
+            smp = anim["samplers"][ch["sampler"]]
+            times = _accessor(doc, bufs, smp["input"]).reshape(-1).astype(np.float32)
+            values = _accessor(doc, bufs, smp["output"]).astype(np.float32)
+            out.setdefault(ch["target"]["node"], {})[path] = (times, values)
+    return out
 
 
 def _load_image(doc, base, bufs, index):
@@ -183,44 +277,56 @@ def load_gltf(path, width_over_height=16 / 9):
             ids.append(len(prims))
             prims.append((mesh_obj, int(p.get("material", -1)) + 1, extra))
         mesh_prims.append(ids)
-    # ---- scene graph ------------------------------------------------------------------------------------------------
-    instances, lights, cameras = [], [], []
+    # ---- scene graph + animations -------------------------------------------------------------------------------
     light_defs = doc.get("extensions", {}).get("KHR_lights_punctual", {}).get("lights", [])
+    animations = _load_animations(doc, bufs)
 
-    def walk(node_id, parent):
-        node = doc["nodes"][node_id]
-        m = parent @ _node_matrix(node)
-        lid = node.get("extensions", {}).get("KHR_lights_punctual", {}).get("light")
-        kinds = (node.get("mesh") is not None) + (node.get("camera") is not None) + (lid is not None)
-        if kinds > 1:
-            raise GltfError("an object can only be one of mesh, camera or light")  # loader.cu:563
-        if node.get("mesh") is not None:
-            for vao in mesh_prims[node["mesh"]]:
-                instances.append((vao, prims[vao][1], m))
-        elif node.get("camera") is not None:
-            cam = doc["cameras"][node["camera"]]
-            if cam.get("type") == "perspective":
-                cameras.append((m, cam["perspective"]))
-        elif lid is not None:
-            ld = light_defs[lid]
-            inten = float(ld.get("intensity", 1.0))
-            col = ld.get("color", [1, 1, 1])
-            d = m @ np.array([0, 0, -1, 0.0])
-            d = d[:3] / np.linalg.norm(d[:3])
-            kind = ld["type"]
-            if kind not in ("point", "spot", "directional"):
-                raise GltfError("unexpected light type")
-            lights.append(dict(type=abi.LIGHT_DIRECTIONAL if kind == "directional" else abi.LIGHT_POINT,  # spot -> POINT
-                               intensity=tuple(float(c) * inten for c in col), direction=tuple(d), position=tuple(m[:3, 3])))
-        for c in node.get("children", []):
-            walk(c, m)
+    def walk_scene(time):
+        instances, lights, cameras = [], [], []
 
-    scene_def = doc["scenes"][doc.get("scene", 0)]
-    for n in scene_def["nodes"]:
-        walk(n, np.eye(4))
-    if not cameras:
-        raise GltfError("no active camera")  # hierarchy.hpp:285
-    cam_m, persp = cameras[0]
+        def walk(node_id, parent):
+            node = doc["nodes"][node_id]
+            m = parent @ _node_matrix(node, animations.get(node_id), time)
+            lid = node.get("extensions", {}).get("KHR_lights_punctual", {}).get("light")
+            kinds = (node.get("mesh") is not None) + (node.get("camera") is not None) + (lid is not None)
+            if kinds > 1:
+                raise GltfError("an object can only be one of mesh, camera or light")  # loader.cu:563
+            if node.get("mesh") is not None:
+                for vao in mesh_prims[node["mesh"]]:
+                    instances.append((vao, prims[vao][1], m))
+            elif node.get("camera") is not None:
+                cam = doc["cameras"][node["camera"]]
+                if cam.get("type") == "perspective":
+                    cameras.append((m, cam["perspective"]))
+            elif lid is not None:
+                ld = light_defs[lid]
+                inten = float(ld.get("intensity", 1.0))
+                col = ld.get("color", [1, 1, 1])
+                d = m @ np.array([0, 0, -1, 0.0])
+                d = d[:3] / np.linalg.norm(d[:3])
+                kind = ld["type"]
+                if kind not in ("point", "spot", "directional"):
+                    raise GltfError("unexpected light type")
+                lights.append(dict(type=abi.LIGHT_DIRECTIONAL if kind == "directional" else abi.LIGHT_POINT,  # spot -> POINT
+                                   intensity=tuple(float(c) * inten for c in col), direction=tuple(d), position=tuple(m[:3, 3])))
+            for c in node.get("children", []):
+                walk(c, m)
+
+        for n in doc["scenes"][doc.get("scene", 0)]["nodes"]:
+            walk(n, np.eye(4))
+        if not cameras:
+            raise GltfError("no active camera")  # hierarchy.hpp:285
+        return instances, lights, cameras[0]
+
+    def set_camera(sc, cam_m):
+        # Camera::world_to_view (hierarchy.hpp:67-71): lookAt(M*origin, M*(0,0,-1,1), M*(0,1,0,0))
+        eye = cam_m[:3, 3]
+        fwd = (cam_m @ np.array([0, 0, -1, 0.0]))[:3]
+        w2v = scenes.look_at(eye, eye + fwd, (cam_m @ np.array([0, 1, 0, 0.0]))[:3])
+        sc.camera_W2V = w2v.astype(np.float32)
+        sc.camera_L2W = np.linalg.inv(w2v).astype(np.float32)
+
+    instances, lights, (cam_m, persp) = walk_scene(None)
     eye = cam_m[:3, 3]
     fwd = (cam_m @ np.array([0, 0, -1, 0.0]))[:3]
     meshes = [p[0] for p in prims]
@@ -237,10 +343,19 @@ def load_gltf(path, width_over_height=16 / 9):
         if "uv1" in extra:
             sc.vertices["uv1"][vo:vo + n] = extra["uv1"]
         vo += n
-    # camera orientation straight from the node matrix (assemble() assumed +y up)
-    w2v = scenes.look_at(eye, eye + fwd, (cam_m @ np.array([0, 1, 0, 0.0]))[:3])
-    sc.camera_W2V = w2v.astype(np.float32)
-    sc.camera_L2W = np.linalg.inv(w2v).astype(np.float32)
+    set_camera(sc, cam_m)
+
+    def pose(time):
+        """The RDScene at `time` seconds: Object::apply_animation down the tree (hierarchy.hpp:135-143), then
+        build_rendering_scene (:222-290).  Resources (VBO/EBO/BLAS/materials) do not change."""
+        inst, lts, (cm, _) = walk_scene(float(time))
+        out = scenes.with_instance_transforms(sc, {i: m for i, (_, _, m) in enumerate(inst)})
+        out.lights = lts
+        set_camera(out, cm)
+        return out
+
+    sc.pose = pose
+    sc.animated_nodes = sorted(animations)
     return sc
 
 

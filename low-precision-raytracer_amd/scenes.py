@@ -548,3 +548,24 @@ def textured_scene():
 
 
 SCENES = {"textured": textured_scene, "cornell": cornell_box, "sponza_like": sponza_like, "small_test": small_test_scene}
+
+
+def with_instance_transforms(sc, transforms):
+    """The RDScene of another frame: same resources, new local-to-world matrices for some instances
+    ({instance index: 4x4}); W2L and the world AABBs follow as in hierarchy::Scene::build_rendering_scene
+    (rt/rtrt/hierarchy.hpp:236-247)."""
+    import copy
+    out = copy.copy(sc)
+    out.objects = [dict(o) for o in sc.objects]
+    out.aabbs = sc.aabbs.copy()
+    for i, l2w in transforms.items():
+        l2w32 = np.asarray(l2w, dtype=np.float64).astype(np.float32)
+        o = out.objects[i]
+        o["L2W"] = l2w32
+        o["W2L"] = np.linalg.inv(l2w32.astype(np.float64)).astype(np.float32)
+        lo, hi = sc.local_aabbs[o["objectid"]][:3], sc.local_aabbs[o["objectid"]][3:]
+        corners = np.array([[(lo, hi)[(c >> k) & 1][k] for k in range(3)] + [1.0] for c in range(8)], dtype=np.float32)
+        wc = (l2w32 @ corners.T).T
+        wc = wc[:, :3] / wc[:, 3:4]
+        out.aabbs[i] = np.concatenate([wc.min(axis=0), wc.max(axis=0)]).astype(np.float32)
+    return out

@@ -164,3 +164,62 @@ def test_glb_and_errors(tmp_path):
     bad["scenes"][0]["nodes"] = [0]
     with pytest.raises(gltf.GltfError, match="no active camera"):
         gltf.load_gltf(_write(tmp_path, bad, "bad3.gltf"))
+
+
+def _animated_doc():
+    doc = _tiny_doc()
+    raw = bytearray(base64.b64decode(doc["buffers"][0]["uri"].split(",", 1)[1]))
+
+    def add(arr, atype):
+        while len(raw) % 4:
+            raw.append(0)
+        doc["bufferViews"].append(dict(buffer=0, byteOffset=len(raw), byteLength=arr.nbytes))
+        raw.extend(arr.tobytes())
+        doc["accessors"].append(dict(bufferView=len(doc["bufferViews"]) - 1, componentType=5126, count=len(arr), type=atype))
+        return len(doc["accessors"]) - 1
+
+    t = add(np.array([0.0, 2.0], dtype=np.float32), "SCALAR")
+    tr = add(np.array([[0, 0, -1], [0, 0, -3]], dtype=np.float32), "VEC3")
+    t3 = add(np.array([0.0, 1.0, 4.0], dtype=np.float32), "SCALAR")
+    h = np.sqrt(0.5)
+    rot = add(np.array([[0, 0, 0, 1], [0, h, 0, h], [0, 1, 0, 0]], dtype=np.float32), "VEC4")
+    t1 = add(np.array([0.5], dtype=np.float32), "SCALAR")
+    sc1 = add(np.array([[3, 3, 3]], dtype=np.float32), "VEC3")
+    doc["animations"] = [dict(samplers=[dict(input=t, output=tr), dict(input=t3, output=rot), dict(input=t1, output=sc1)],
+                              channels=[dict(sampler=0, target=dict(node=1, path="translation")),
+                                        dict(sampler=1, target=dict(node=2, path="rotation")),
+                                        dict(sampler=2, target=dict(node=1, path="scale")),
+                                        dict(sampler=0, target=dict(node=1, path="weights"))])]
+    doc["buffers"][0] = dict(byteLength=len(raw), uri="data:application/octet-stream;base64," + base64.b64encode(bytes(raw)).decode())
+    return doc
+
+
+def test_animation_sampling_and_pose(tmp_path):
+    """load_animations (loader.cu:692-733) + Sampler::sample / apply_animation (hierarchy.hpp:81-143)."""
+    sc = gltf.load_gltf(_write(tmp_path, _animated_doc()))
+    assert sc.animated_nodes == [1, 2]
+    parent = sc.objects[0]["L2W"].astype(np.float64)
+    # loading does not apply the animation: the child sits at its node translation (0, 0, -1)
+    assert np.allclose(sc.objects[2]["L2W"], parent @ np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, -1], [0, 0, 0, 1.0]]), atol=1e-6)
+    at1 = sc.pose(1.0)
+    # child node 1: translation halfway (0,0,-2); the single-key scale channel gives (3,3,3) at any time
+    want = parent @ np.array([[3, 0, 0, 0], [0, 3, 0, 0], [0, 0, 3, -2], [0, 0, 0, 1.0]])
+    assert np.allclose(at1.objects[2]["L2W"], want, atol=1e-5) and np.allclose(at1.objects[3]["L2W"], want, atol=1e-5)
+    assert np.array_equal(at1.objects[0]["L2W"], sc.objects[0]["L2W"])                        # the parent is not animated
+    assert np.allclose(at1.objects[2]["W2L"].astype(np.float64) @ at1.objects[2]["L2W"], np.eye(4), atol=1e-5)
+    assert not np.array_equal(at1.aabbs[2], sc.aabbs[2]) and np.array_equal(at1.aabbs[0], sc.aabbs[0])
+    # time wraps past the last key: 2.5 s -> 0.5 s -> z = -1.5
+    assert np.allclose(sc.pose(2.5).objects[2]["L2W"][:3, 3], (parent @ [0, 0, -1.5, 1])[:3], atol=1e-5)
+    # camera node 2: rotation key 1 at t = 1 is a quarter turn about +y: the camera looks down -x
+    cam = sc.pose(1.0)
+    assert np.allclose(cam.camera_L2W[:3, 3], [0, 0, 5], atol=1e-6)
+    assert np.allclose(cam.camera_L2W @ np.array([0, 0, -1, 0], dtype=np.float32), [-1, 0, 0, 0], atol=1e-5)
+    # between keys the quaternion is lerped WITHOUT renormalising and handed to angle/axis as is (glm::lerp, :115)
+    half = sc.pose(0.5)
+    q = 0.5 * np.array([0, 0, 0, 1.0]) + 0.5 * np.array([0, np.sqrt(0.5), 0, np.sqrt(0.5)])
+    angle = 2 * np.arcsin(np.linalg.norm(q[:3])) if abs(q[3]) > np.cos(0.5) else 2 * np.arccos(q[3])
+    fwd = half.camera_L2W @ np.array([0, 0, -1, 0], dtype=np.float32)
+    assert np.allclose(fwd[:3], [-np.sin(angle), 0, -np.cos(angle)], atol=1e-5)
+    assert abs(angle - np.pi / 4) > 1e-3                                                      # not the slerp angle
+    # the geometry arrays are shared, not rebuilt
+    assert at1.vertices is sc.vertices and at1.indices is sc.indices
