@@ -569,3 +569,27 @@ def with_instance_transforms(sc, transforms):
         wc = wc[:, :3] / wc[:, 3:4]
         out.aabbs[i] = np.concatenate([wc.min(axis=0), wc.max(axis=0)]).astype(np.float32)
     return out
+
+
+def write_blob(sc, width, height, path):
+    """Flat little-endian dump of what the loader + scene manager hand to the renderer (examples/compat_demo.cpp
+    reads it): "LPRTSCN1", six uint32 counts, then vertices, indices, VAOs, materials, objects, AABBs, lights, camera,
+    world-to-clip, each array in its include/lprt.h layout."""
+    import ctypes as C
+    vaos, mats, objs, boxes, lights = sc.c_vaos(), sc.c_materials(), sc.c_objects(), sc.c_aabbs(), sc.c_lights()
+    cam = sc.c_camera(width, height)
+    w2c = np.ascontiguousarray(sc.transform_W2C(width, height), dtype=np.float32)
+    with open(path, "wb") as f:
+        f.write(b"LPRTSCN1")
+        f.write(np.array([len(sc.vertices), len(sc.indices), len(sc.vaos), len(sc.materials), len(sc.objects), len(sc.lights)],
+                         dtype="<u4").tobytes())
+        f.write(np.ascontiguousarray(sc.vertices).tobytes())
+        f.write(np.ascontiguousarray(sc.indices, dtype="<u4").tobytes())
+        f.write(bytes(vaos))
+        f.write(bytes(mats))
+        f.write(bytes(objs))
+        f.write(bytes(boxes))
+        f.write(bytes(lights)[:C.sizeof(abi.Light) * len(sc.lights)])
+        f.write(bytes(cam))
+        f.write(w2c.tobytes())
+    return path

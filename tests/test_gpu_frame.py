@@ -352,3 +352,27 @@ def test_moving_objects_and_camera_reproject_like_the_oracle(cornell, prec):
         still.set_scene(cornell)
         still.render(abi.default_settings(spp=1))
     assert rel_l2(still.read("OUTPUT"), r.read("OUTPUT")) > 1e-2
+
+
+@pytest.mark.parametrize("prec,name", [(abi.F32, "f32"), (abi.F16, "f16")])
+def test_cpp_host_over_compat_header_renders_the_same_frames(cornell, tmp_path, prec, name):
+    """§8(f) rank 3: examples/compat_demo.cpp drives Renderer<DataT> / RDResource / RDScene / CUDARenderGIData of
+    include/lprt_compat.hpp; two frames at 2 spp come out bit-identical to the Python binding's."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "compat_demo")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(root, "examples"), "compat_demo"], check=True)
+    W, H = 128, 80
+    blob = scenes.write_blob(cornell, W, H, str(tmp_path / "cornell.blob"))
+    out = str(tmp_path / "out.raw")
+    p = subprocess.run([exe, blob, str(W), str(H), "2", "2", name, out], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    assert "last BLAS: 2 triangles" in p.stdout
+    got = np.fromfile(out, dtype=np.float32).reshape(H, W, 4)
+    r = lprt_amd.Renderer(W, H, prec)
+    r.load_scene(cornell)
+    for _ in range(2):
+        r.set_scene(cornell)
+        r.render(abi.default_settings(spp=2))
+    assert np.array_equal(got, r.read("OUTPUT"), equal_nan=True)

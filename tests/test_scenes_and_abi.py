@@ -106,3 +106,23 @@ def test_image_writer_roundtrip(tmp_path):
     assert png[4, 1, 1] == int(np.clip(a[0, 1, 1], 0, 1) * 255 + 0.5)
     image_io.save_pfm(str(tmp_path / "a.pfm"), np.nan_to_num(a))
     assert np.array_equal(image_io.load_pfm(str(tmp_path / "a.pfm")), np.nan_to_num(a)[..., :3])
+
+
+def test_compat_header_and_demo_build_and_fail_loudly_without_gpu(tmp_path):
+    """include/lprt_compat.hpp (reference-named host types over the C-ABI) compiles as plain C++17, and the example
+    host program reports the library's error instead of producing a frame when no GPU is there."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "lprt_compat.hpp"\nusing namespace lprt_compat;\n'
+                   'static_assert(sizeof(RDVertex<float16>) == 64 && sizeof(CUDAMeshVAO) == 16, "layouts");\n'
+                   'template class Renderer<float>;\ntemplate class Renderer<float16>;\nint main() { return 0; }\n')
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(root, "include"), str(src)], check=True)
+    subprocess.run(["make", "-C", os.path.join(root, "examples"), "compat_demo"], check=True, capture_output=True)
+    from lprt_amd import scenes
+    blob = scenes.write_blob(scenes.cornell_box(), 64, 48, str(tmp_path / "c.blob"))
+    import torch
+    if not torch.cuda.is_available():
+        p = subprocess.run([os.path.join(root, "examples", "compat_demo"), blob, "64", "48", "1", "1", "f32", str(tmp_path / "o.raw")],
+                           capture_output=True, text=True)
+        assert p.returncode == 4 and "lprt_create" in p.stderr and not (tmp_path / "o.raw").exists()
