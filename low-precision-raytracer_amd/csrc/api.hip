@@ -210,14 +210,6 @@ template <typename T> struct Impl : CtxBase {
         fb.lc_multiplier = carve<V4<T>>(off, n * LPRT_MAX_DIRECT_LIGHT);
         fb.lc_mask = carve<uint8_t>(off, n);
         fb.sc_position = carve<V4<T>>(off, n);
-        fb.sc_normal = carve<V4<T>>(off, n);
-        fb.sc_tangent = carve<V4<T>>(off, n);
-        fb.sc_color = carve<V4<T>>(off, n);
-        fb.sc_uv = carve<V4<T>>(off, n);
-        fb.sc_type = carve<uint32_t>(off, n);
-        fb.sc_materialid = carve<uint32_t>(off, n);
-        fb.sc_objid = carve<uint32_t>(off, n);
-        fb.sc_offset = carve<uint32_t>(off, n);
         fb.albedo = carve<V4<T>>(off, n);
         fb.color_inprogress = carve<V4<T>>(off, n);
         taa_a = carve<V4<T>>(off, n);
@@ -327,14 +319,17 @@ template <typename T> struct Impl : CtxBase {
                 fb.rng_state = d_rng_planes.as<uint32_t>() + (size_t)next_plane * 5 * npix;
                 d_b = seed_d[next_plane++];
             }
-            stage(LPRT_STAGE_SHADE1, [&] { launch_shade<T>(stream, sc, fb, true, !fs.gi_on, d_b); });
-            stage(LPRT_STAGE_TRACE_DI1, [&] { launch_trace_di<T>(stream, sc, fb, true, stage_counters(LPRT_STAGE_TRACE_DI1)); });
+            stage(LPRT_STAGE_SHADE1, [&] { launch_shade<T>(stream, sc, fb, !fs.gi_on, d_b); });
+            stage(LPRT_STAGE_TRACE_DI1, [&] {
+                launch_trace_di<T>(stream, sc, fb, true, fs.gi_on != 0, fs.add_direct_out != 0, s, spp, stage_counters(LPRT_STAGE_TRACE_DI1));
+            });
             if (fs.gi_on) {
+                // trace_gi + shade #2 of the hit in one kernel; trace_di #2 + write_clean_color + spp mean in the next
                 stage(LPRT_STAGE_TRACE_GI, [&] { launch_trace_gi<T>(stream, sc, fb, stage_counters(LPRT_STAGE_TRACE_GI)); });
-                stage(LPRT_STAGE_SHADE2, [&] { launch_shade<T>(stream, sc, fb, false, true, 0u); });
-                stage(LPRT_STAGE_TRACE_DI2, [&] { launch_trace_di<T>(stream, sc, fb, false, stage_counters(LPRT_STAGE_TRACE_DI2)); });
+                stage(LPRT_STAGE_TRACE_DI2, [&] {
+                    launch_trace_di<T>(stream, sc, fb, false, true, fs.add_direct_out != 0, s, spp, stage_counters(LPRT_STAGE_TRACE_DI2));
+                });
             }
-            stage(LPRT_STAGE_COMPOSE, [&] { launch_compose<T>(stream, fb, fs.gi_on != 0, fs.add_direct_out != 0, s, spp); });
         }
         const V4<T> *res0 = fb.lobe[0].cv_a, *res1 = fb.lobe[1].cv_a;
         svgf_ran = fs.svgf != 0;

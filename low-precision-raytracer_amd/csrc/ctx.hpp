@@ -94,9 +94,9 @@ template <typename T> struct FrameDev {
     V4<T> *lc_dir_maxt;     // direction.xyz, maximum_t
     V4<T> *lc_multiplier;   // material_multiplier.xyz
     uint8_t *lc_mask;       // bit s set: slot s active (slot != 255)
-    // PixelShaderInput (cuda.hpp:1034-1048), SoA
-    V4<T> *sc_position, *sc_normal, *sc_tangent, *sc_color, *sc_uv;
-    uint32_t *sc_type, *sc_materialid, *sc_objid, *sc_offset;
+    // PixelShaderInput (cuda.hpp:1034-1048) lives in registers between trace_gi and shade #2; only the hit position is
+    // kept, as the source of round 1's shadow rays
+    V4<T> *sc_position;
     // filterable cache
     V4<T> *albedo, *color_inprogress, *taa_history;
     float4 *acc_color, *acc_gi_colored, *acc_gi_white; // spp accumulators (f32)

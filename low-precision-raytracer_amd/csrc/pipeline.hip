@@ -185,58 +185,29 @@ __global__ void __launch_bounds__(256) k_temporal_map(SceneDev<T> sc, FrameDev<T
 }
 
 // ---- S: shade<T,4,FIRST_ROUND,NO_GI> (cuda.hpp:1751-2056) ----------------------------------------------------
+// The surface point shade() works on: a G-buffer texel (round 0, loaded by k_shade) or the interpolated GI hit
+// (round 1, handed over in registers by k_trace_gi: the PixelShaderInput record never goes through memory).
+template <typename T> struct ShadeIn {
+    V3<T> position, raw_normal, raw_tangent, vertex_color;
+    V4<T> uv4;
+    MaterialT<T> material;
+    uint32_t inobject_offset, objectid;
+    bool live, sky_pixel;
+};
+
 template <typename T, bool FIRST, bool NO_GI>
-__global__ void __launch_bounds__(256) k_shade(SceneDev<T> sc, FrameDev<T> fb, uint32_t rng_d) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+LPRT_DEV void shade_and_store(const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t p, uint32_t rng_d, const ShadeIn<T> &in) {
     const uint32_t npix = fb.win.npix();
-    if (p >= npix)
-        return;
     const uint32_t x = p % fb.win.W, y = fb.win.row_begin + p / fb.win.W;
     const T zero = (T)0, one = (T)1;
     const V4<T> zero4 = mk4(zero, zero, zero, zero);
     V4<T> *intensity = FIRST ? fb.intensity0 : fb.intensity1;
-
-    V3<T> position, raw_normal, raw_tangent, vertex_color;
-    MaterialT<T> material;
-    uint32_t inscene_objid, inobject_offset, objectid;
-    V4<T> uv4 = zero4;
-    bool live = true, sky_pixel = false;
-    if (FIRST) {
-        const uint32_t c4 = fb.g_color[p];
-        // to_color_float (cuda.hpp:890-892): DataT(c / 255.f)
-        vertex_color = mk3(cvt<T>((float)(c4 & 255u) / 255.f), cvt<T>((float)((c4 >> 8) & 255u) / 255.f),
-                           cvt<T>((float)((c4 >> 16) & 255u) / 255.f));
-        if ((c4 >> 24) == 0) {
-            live = false; // empty pixel (cuda.hpp:1781-1796)
-            sky_pixel = true;
-        } else {
-            uv4 = fb.g_uv[p];
-            inscene_objid = fb.g_objid[p];
-            inobject_offset = fb.g_offset[p];
-            position = xyz(fb.g_position[p]);
-            raw_normal = xyz(fb.g_normal_depth[p]);
-            raw_tangent = xyz(fb.g_tangent[p]);
-            const ObjConst<T> *oc = sc.objects + inscene_objid;
-            material = sc.materials[oc->materialid];
-            objectid = oc->objectid;
-        }
-    } else {
-        const uint32_t type = fb.sc_type[p];
-        if (type != 1u) { // INVALID or SKYBOX (cuda.hpp:1819-1833); Q5: invalid skybox contributes 0
-            live = false;
-            sky_pixel = type == 2u;
-        } else {
-            uv4 = fb.sc_uv[p];
-            vertex_color = xyz(fb.sc_color[p]);
-            inscene_objid = fb.sc_objid[p];
-            inobject_offset = fb.sc_offset[p];
-            position = xyz(fb.sc_position[p]);
-            raw_normal = xyz(fb.sc_normal[p]);
-            raw_tangent = xyz(fb.sc_tangent[p]);
-            material = sc.materials[fb.sc_materialid[p]];
-            objectid = sc.objects[inscene_objid].objectid;
-        }
-    }
+    const V3<T> position = in.position, raw_normal = in.raw_normal, raw_tangent = in.raw_tangent, vertex_color = in.vertex_color;
+    const MaterialT<T> &material = in.material;
+    const uint32_t inobject_offset = in.inobject_offset, objectid = in.objectid;
+    const V4<T> uv4 = in.uv4;
+    bool live = in.live;
+    const bool sky_pixel = in.sky_pixel;
     V3<T> color, normal, view_dir;
     if (live) {
         color = ld3(material.color);
@@ -403,6 +374,8 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev<T> sc, FrameDev<T> fb, u
     fb.lc_mask[p] = (uint8_t)mask;
     intensity[p] = o_intensity;
     fb.skips[p] = o_skip;
+    if (!FIRST) // the shadow rays of round 1 start at the GI hit
+        fb.sc_position[p] = live ? mk4(position.x, position.y, position.z, zero) : zero4;
     if (FIRST) {
         fb.albedo[p] = o_albedo;
         fb.gi_valid[p] = (uint8_t)o_gi_valid; // DEVIATION Q13: untouched GI commands are invalid
@@ -412,17 +385,55 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev<T> sc, FrameDev<T> fb, u
     }
 }
 
-// ---- TD + A: trace_di_light + accumulate_di_light (cuda.hpp:2058-2081, 2143-2159) ------------------------------
-template <typename T, bool FIRST, bool COUNT>
-__global__ void __launch_bounds__(256) k_trace_di(SceneDev<T> sc, FrameDev<T> fb, Counters *counters) {
+template <typename T, bool NO_GI>
+__global__ void __launch_bounds__(256) k_shade(SceneDev<T> sc, FrameDev<T> fb, uint32_t rng_d) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= fb.win.npix())
+        return;
+    const T zero = (T)0;
+    ShadeIn<T> in;
+    in.uv4 = mk4(zero, zero, zero, zero);
+    in.live = true;
+    in.sky_pixel = false;
+    in.inobject_offset = 0u;
+    in.objectid = 0u;
+    const uint32_t c4 = fb.g_color[p];
+    // to_color_float (cuda.hpp:890-892): DataT(c / 255.f)
+    in.vertex_color = mk3(cvt<T>((float)(c4 & 255u) / 255.f), cvt<T>((float)((c4 >> 8) & 255u) / 255.f), cvt<T>((float)((c4 >> 16) & 255u) / 255.f));
+    if ((c4 >> 24) == 0) {
+        in.live = false; // empty pixel (cuda.hpp:1781-1796)
+        in.sky_pixel = true;
+    } else {
+        in.uv4 = fb.g_uv[p];
+        in.inobject_offset = fb.g_offset[p];
+        in.position = xyz(fb.g_position[p]);
+        in.raw_normal = xyz(fb.g_normal_depth[p]);
+        in.raw_tangent = xyz(fb.g_tangent[p]);
+        const ObjConst<T> *oc = sc.objects + fb.g_objid[p];
+        in.material = sc.materials[oc->materialid];
+        in.objectid = oc->objectid;
+    }
+    shade_and_store<T, true, NO_GI>(sc, fb, p, rng_d, in);
+}
+
+// ---- TD + A (+ W): trace_di_light + accumulate_di_light (cuda.hpp:2058-2081, 2143-2159); the LAST round of a sample
+// also runs write_clean_color (cuda.hpp:2170-2199) and the build-side spp mean on the radiance it just completed:
+// sample s of n accumulates in f32 in sample order; the last sample divides once and rounds once to DataT.
+struct ComposeArgs {
+    int gi_on, add_direct_out;
+    uint32_t sample, spp;
+};
+template <typename T, bool FIRST, bool COMPOSE, bool COUNT>
+__global__ void __launch_bounds__(256) k_trace_di(SceneDev<T> sc, FrameDev<T> fb, ComposeArgs ca, Counters *counters) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t npix = fb.win.npix();
     Cnt<COUNT> cnt;
     if (p < npix) {
+        const T zero = (T)0, one = (T)1;
+        V4<T> *intensity = FIRST ? fb.intensity0 : fb.intensity1;
         const uint32_t mask = fb.lc_mask[p];
+        V4<T> cur = intensity[p];
         if (mask) {
-            const T zero = (T)0, one = (T)1;
-            V4<T> *intensity = FIRST ? fb.intensity0 : fb.intensity1;
             const V3<T> source = xyz(FIRST ? fb.g_position[p] : fb.sc_position[p]);
             const uint2 skip = fb.skips[p];
             V3<T> fc = zero3<T>(); // accumulate_di_light: final_color = {} ; += di_intensity[4p+i]
@@ -437,91 +448,91 @@ __global__ void __launch_bounds__(256) k_trace_di(SceneDev<T> sc, FrameDev<T> fb
                 }
                 fc = fc + di;
             }
-            V4<T> cur = intensity[p];
-            intensity[p] = mk4(cur.x + fc.x, cur.y + fc.y, cur.z + fc.z, zero);
+            cur = mk4(cur.x + fc.x, cur.y + fc.y, cur.z + fc.z, zero);
+            intensity[p] = cur;
+        }
+        if (COMPOSE) {
+            V3<T> fc = zero3<T>(), colored = zero3<T>(), white = zero3<T>();
+            const V4<T> m0 = fb.gi_multiplier[p];
+            if (ca.add_direct_out)
+                fc = FIRST ? xyz(cur) : xyz(fb.intensity0[p]);
+            const V3<T> i1 = FIRST ? zero3<T>() : xyz(cur); // gi off: there is no second round
+            if (tisnan(m0.z)) {
+                colored = m0.x * i1;
+                white = m0.y * i1;
+            } else if (ca.add_direct_out) {
+                fc = fc + elemul(i1, xyz(m0));
+            }
+            float4 ac = make_float4((float)fc.x, (float)fc.y, (float)fc.z, 0.f);
+            float4 ag = make_float4((float)colored.x, (float)colored.y, (float)colored.z, 0.f);
+            float4 aw = make_float4((float)white.x, (float)white.y, (float)white.z, 0.f);
+            if (ca.sample > 0) {
+                float4 o = fb.acc_color[p];
+                ac = make_float4(o.x + ac.x, o.y + ac.y, o.z + ac.z, 0.f);
+                o = fb.acc_gi_colored[p];
+                ag = make_float4(o.x + ag.x, o.y + ag.y, o.z + ag.z, 0.f);
+                o = fb.acc_gi_white[p];
+                aw = make_float4(o.x + aw.x, o.y + aw.y, o.z + aw.z, 0.f);
+            }
+            if (ca.sample + 1 < ca.spp) {
+                fb.acc_color[p] = ac;
+                fb.acc_gi_colored[p] = ag;
+                fb.acc_gi_white[p] = aw;
+            } else {
+                const float n = (float)ca.spp;
+                V4<T> c = mk4(cvt<T>(ac.x / n), cvt<T>(ac.y / n), cvt<T>(ac.z / n), zero);
+                V4<T> g = mk4(cvt<T>(ag.x / n), cvt<T>(ag.y / n), cvt<T>(ag.z / n), zero);
+                V4<T> w = mk4(cvt<T>(aw.x / n), cvt<T>(aw.y / n), cvt<T>(aw.z / n), zero);
+                fb.color_inprogress[p] = c;
+                fb.lobe[0].cv_a[p] = g;
+                fb.lobe[1].cv_a[p] = w;
+                fb.raw_color[p] = c;
+                fb.raw_gi_colored[p] = g;
+                fb.raw_gi_white[p] = w;
+            }
         }
     }
     flush_counters<COUNT>(cnt, counters);
 }
 
-// ---- TG: trace_gi (cuda.hpp:2083-2141) ---------------------------------------------------------------------------
+// ---- TG + S2: trace_gi (cuda.hpp:2083-2141) followed, in the same thread, by shade #2 of the hit ---------------------
+// The reference stores a PixelShaderInput record per pixel and launches shade<false,true> over it; nothing but the
+// traversal result is live here when the traversal ends, so the record stays in registers.
 template <typename T, bool COUNT>
 __global__ void __launch_bounds__(256) k_trace_gi(SceneDev<T> sc, FrameDev<T> fb, Counters *counters) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     Cnt<COUNT> cnt;
     if (p < fb.win.npix()) {
-        uint32_t type = 0; // PixelShaderInput::INVALID
+        const T zero = (T)0;
+        ShadeIn<T> in; // type INVALID unless the ray below says otherwise
+        in.uv4 = mk4(zero, zero, zero, zero);
+        in.live = false;
+        in.sky_pixel = false;
+        in.inobject_offset = 0u;
+        in.objectid = 0u;
         if (fb.gi_valid[p]) {
             const uint2 skip = fb.skips[p];
             RayT<T> ray{xyz(fb.g_position[p]), xyz(fb.gi_direction[p])};
             Isect<T> is = cast_ray<T, false, COUNT>(sc, ray, skip.x, skip.y, cvt<T>(ray_moveforward_t<T>()), cvt<T>(1e5f), cnt);
             if (is.hit) {
                 HitAttr<T> h = interpolate_hit(sc, is);
-                const T zero = (T)0;
-                fb.sc_normal[p] = mk4(h.normal.x, h.normal.y, h.normal.z, zero);
-                fb.sc_tangent[p] = mk4(h.tangent.x, h.tangent.y, h.tangent.z, zero);
-                fb.sc_position[p] = mk4(h.position.x, h.position.y, h.position.z, zero);
-                fb.sc_color[p] = mk4(h.color.x, h.color.y, h.color.z, zero);
-                fb.sc_uv[p] = mk4(h.uv0.x, h.uv0.y, h.uv1.x, h.uv1.y);
-                fb.sc_objid[p] = is.inscene_objid;
-                fb.sc_offset[p] = is.inobject_offset;
-                fb.sc_materialid[p] = sc.objects[is.inscene_objid].materialid;
-                type = 1; // COMMON
+                in.position = h.position;
+                in.raw_normal = h.normal;
+                in.raw_tangent = h.tangent;
+                in.vertex_color = h.color;
+                in.uv4 = mk4(h.uv0.x, h.uv0.y, h.uv1.x, h.uv1.y);
+                const ObjConst<T> *oc = sc.objects + is.inscene_objid;
+                in.material = sc.materials[oc->materialid];
+                in.objectid = oc->objectid;
+                in.inobject_offset = is.inobject_offset;
+                in.live = true; // COMMON
             } else {
-                type = 2; // SKYBOX
+                in.sky_pixel = true; // SKYBOX
             }
         }
-        fb.sc_type[p] = type;
+        shade_and_store<T, false, true>(sc, fb, p, 0u, in);
     }
     flush_counters<COUNT>(cnt, counters);
-}
-
-// ---- write_clean_color (cuda.hpp:2170-2199) + the build-side spp mean --------------------------
-// sample s of n: accumulate in f32 in sample order; the last sample divides once and rounds once to DataT.
-template <typename T>
-__global__ void __launch_bounds__(256) k_compose(FrameDev<T> fb, int gi_on, int add_direct_out, uint32_t sample, uint32_t spp) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= fb.win.npix())
-        return;
-    const T zero = (T)0;
-    V3<T> fc = zero3<T>(), colored = zero3<T>(), white = zero3<T>();
-    const V4<T> m0 = fb.gi_multiplier[p];
-    if (add_direct_out)
-        fc = xyz(fb.intensity0[p]);
-    V3<T> i1 = gi_on ? xyz(fb.intensity1[p]) : zero3<T>();
-    if (tisnan(m0.z)) {
-        colored = m0.x * i1;
-        white = m0.y * i1;
-    } else if (add_direct_out) {
-        fc = fc + elemul(i1, xyz(m0));
-    }
-    float4 ac = make_float4((float)fc.x, (float)fc.y, (float)fc.z, 0.f);
-    float4 ag = make_float4((float)colored.x, (float)colored.y, (float)colored.z, 0.f);
-    float4 aw = make_float4((float)white.x, (float)white.y, (float)white.z, 0.f);
-    if (sample > 0) {
-        float4 o = fb.acc_color[p];
-        ac = make_float4(o.x + ac.x, o.y + ac.y, o.z + ac.z, 0.f);
-        o = fb.acc_gi_colored[p];
-        ag = make_float4(o.x + ag.x, o.y + ag.y, o.z + ag.z, 0.f);
-        o = fb.acc_gi_white[p];
-        aw = make_float4(o.x + aw.x, o.y + aw.y, o.z + aw.z, 0.f);
-    }
-    if (sample + 1 < spp) {
-        fb.acc_color[p] = ac;
-        fb.acc_gi_colored[p] = ag;
-        fb.acc_gi_white[p] = aw;
-    } else {
-        const float n = (float)spp;
-        V4<T> c = mk4(cvt<T>(ac.x / n), cvt<T>(ac.y / n), cvt<T>(ac.z / n), zero);
-        V4<T> g = mk4(cvt<T>(ag.x / n), cvt<T>(ag.y / n), cvt<T>(ag.z / n), zero);
-        V4<T> w = mk4(cvt<T>(aw.x / n), cvt<T>(aw.y / n), cvt<T>(aw.z / n), zero);
-        fb.color_inprogress[p] = c;
-        fb.lobe[0].cv_a[p] = g;
-        fb.lobe[1].cv_a[p] = w;
-        fb.raw_color[p] = c;
-        fb.raw_gi_colored[p] = g;
-        fb.raw_gi_white[p] = w;
-    }
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------
@@ -536,27 +547,34 @@ template <typename T> void launch_fill_gbuffer(hipStream_t st, const SceneDev<T>
 template <typename T> void launch_temporal_map(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, uint32_t rng_d) {
     hipLaunchKernelGGL(k_temporal_map<T>, grid_for(fb.win.npix()), dim3(256), 0, st, sc, fb, first ? 1 : 0, rng_d);
 }
-template <typename T> void launch_shade(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, bool no_gi, uint32_t rng_d) {
+template <typename T> void launch_shade(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool no_gi, uint32_t rng_d) {
     dim3 g = grid_for(fb.win.npix()), b(256);
-    if (first && !no_gi)
-        hipLaunchKernelGGL((k_shade<T, true, false>), g, b, 0, st, sc, fb, rng_d);
-    else if (first)
-        hipLaunchKernelGGL((k_shade<T, true, true>), g, b, 0, st, sc, fb, rng_d);
+    if (!no_gi)
+        hipLaunchKernelGGL((k_shade<T, false>), g, b, 0, st, sc, fb, rng_d);
     else
-        hipLaunchKernelGGL((k_shade<T, false, true>), g, b, 0, st, sc, fb, rng_d);
+        hipLaunchKernelGGL((k_shade<T, true>), g, b, 0, st, sc, fb, rng_d);
 }
-template <typename T> void launch_trace_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, Counters *c) {
+// first: round 0 (composes when GI is off: it is the only round), else round 1 (always composes)
+template <typename T>
+void launch_trace_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, bool gi_on, bool add_direct, uint32_t sample, uint32_t spp,
+                     Counters *c) {
     dim3 g = grid_for(fb.win.npix()), b(256);
-    if (first) {
+    ComposeArgs ca{gi_on ? 1 : 0, add_direct ? 1 : 0, sample, spp};
+    if (first && gi_on) {
         if (c)
-            hipLaunchKernelGGL((k_trace_di<T, true, true>), g, b, 0, st, sc, fb, c);
+            hipLaunchKernelGGL((k_trace_di<T, true, false, true>), g, b, 0, st, sc, fb, ca, c);
         else
-            hipLaunchKernelGGL((k_trace_di<T, true, false>), g, b, 0, st, sc, fb, c);
+            hipLaunchKernelGGL((k_trace_di<T, true, false, false>), g, b, 0, st, sc, fb, ca, c);
+    } else if (first) {
+        if (c)
+            hipLaunchKernelGGL((k_trace_di<T, true, true, true>), g, b, 0, st, sc, fb, ca, c);
+        else
+            hipLaunchKernelGGL((k_trace_di<T, true, true, false>), g, b, 0, st, sc, fb, ca, c);
     } else {
         if (c)
-            hipLaunchKernelGGL((k_trace_di<T, false, true>), g, b, 0, st, sc, fb, c);
+            hipLaunchKernelGGL((k_trace_di<T, false, true, true>), g, b, 0, st, sc, fb, ca, c);
         else
-            hipLaunchKernelGGL((k_trace_di<T, false, false>), g, b, 0, st, sc, fb, c);
+            hipLaunchKernelGGL((k_trace_di<T, false, true, false>), g, b, 0, st, sc, fb, ca, c);
     }
 }
 template <typename T> void launch_trace_gi(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, Counters *c) {
@@ -565,17 +583,13 @@ template <typename T> void launch_trace_gi(hipStream_t st, const SceneDev<T> &sc
     else
         hipLaunchKernelGGL((k_trace_gi<T, false>), grid_for(fb.win.npix()), dim3(256), 0, st, sc, fb, c);
 }
-template <typename T> void launch_compose(hipStream_t st, const FrameDev<T> &fb, bool gi_on, bool add_direct, uint32_t sample, uint32_t spp) {
-    hipLaunchKernelGGL(k_compose<T>, grid_for(fb.win.npix()), dim3(256), 0, st, fb, gi_on ? 1 : 0, add_direct ? 1 : 0, sample, spp);
-}
 
 #define INST(T)                                                                                                        \
     template void launch_fill_gbuffer<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, Counters *);          \
     template void launch_temporal_map<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, uint32_t);      \
-    template void launch_shade<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, bool, uint32_t);       \
-    template void launch_trace_di<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, Counters *);        \
-    template void launch_trace_gi<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, Counters *);              \
-    template void launch_compose<T>(hipStream_t, const FrameDev<T> &, bool, bool, uint32_t, uint32_t);
+    template void launch_shade<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, uint32_t);             \
+    template void launch_trace_di<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, bool, bool, uint32_t, uint32_t, Counters *); \
+    template void launch_trace_gi<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, Counters *);
 INST(float)
 INST(h16)
 #undef INST
