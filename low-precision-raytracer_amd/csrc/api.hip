@@ -494,10 +494,10 @@ template <typename T> struct Impl : CtxBase {
         sc.tlas_depth = tlas.depth;
         sc.n_objects = tlas.n_objects;
         sc.tlas_mode = tlas.n_objects <= 32u ? 1u : 0u;
-        if (const char *m = std::getenv("LPRT_TLAS_MODE")) { // experiment knob: 0 tree, 1 flat, 2 lockstep
+        if (const char *m = std::getenv("LPRT_TLAS_MODE")) { // experiment knob: 0 tree, 1 flat scan
             uint32_t v = (uint32_t)std::atoi(m);
-            if (v == 0u || tlas.n_objects <= 32u)
-                sc.tlas_mode = v > 2u ? 0u : v;
+            if (v == 0u || (v == 1u && tlas.n_objects <= 32u))
+                sc.tlas_mode = v;
         }
         sc.objects = d_objects.template as<ObjConst<T>>();
         sc.blas = geo.d_blas.template as<BlasInfo>();

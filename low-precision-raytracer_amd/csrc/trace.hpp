@@ -297,39 +297,13 @@ LPRT_DEV Isect<T> cast_ray(const SceneDev<T> &sc, const RayT<T> &ray, uint32_t s
             const uint32_t k = (uint32_t)__builtin_ctz(cand);
             cand &= cand - 1u;
             const ObjRec<T> ob = sc.objrecs[k];
-            if (ob.identity) {
-                traverse_blas<T, ANY, COUNT>(sc, ray, rs, ob, skip_vao, skip_off, is, min_distance, max_distance, cnt);
-            } else {
-                const RayT<T> lr = transform_ray(ray, ob.W2L);
-                const RaySlab<T> lrs = make_slab(lr);
-                traverse_blas<T, ANY, COUNT>(sc, lr, lrs, ob, skip_vao, skip_off, is, min_distance, max_distance, cnt);
-            }
+            // one code path for every instance: with an identity W2L the transform returns the ray unchanged
+            // (x*1 + y*0 + z*0 is exact), and a wave mixing walls and boxes does not run the BLAS walk twice
+            const RayT<T> lr = transform_ray(ray, ob.W2L);
+            const RaySlab<T> lrs = make_slab(lr);
+            traverse_blas<T, ANY, COUNT>(sc, lr, lrs, ob, skip_vao, skip_off, is, min_distance, max_distance, cnt);
             if (ANY && is.hit)
                 return is;
-        }
-        return is;
-    }
-    if (sc.tlas_mode == 2u) {
-        // Variant: the same scan in LOCKSTEP across the wave (k wave-uniform: object record, BLAS header and, for 1-3
-        // triangle primitives, the triangle records are scalar loads; lanes whose ray misses box k sit the step out).
-        for (uint32_t k = 0; k < sc.n_objects; k++) {
-            const ObjRec<T> *ob = sc.objrecs + k;
-            if (COUNT)
-                cnt.aabbw++;
-            bool enter = slab_test<T, true>(ob->lo, ob->hi, rs, tmn, tmx) && tmn < max_distance && tmx > min_distance;
-            if (ANY)
-                enter = enter && !is.hit;
-            if (!__builtin_amdgcn_ballot_w64(enter))
-                continue; // no ray of this wave touches object k
-            if (enter) {
-                if (ob->identity) {
-                    traverse_blas<T, ANY, COUNT>(sc, ray, rs, *ob, skip_vao, skip_off, is, min_distance, max_distance, cnt);
-                } else {
-                    const RayT<T> lr = transform_ray(ray, ob->W2L);
-                    const RaySlab<T> lrs = make_slab(lr);
-                    traverse_blas<T, ANY, COUNT>(sc, lr, lrs, *ob, skip_vao, skip_off, is, min_distance, max_distance, cnt);
-                }
-            }
         }
         return is;
     }

@@ -88,7 +88,7 @@ template <typename T> struct SceneDev {
     const ObjSlot<T> *tlas_slots;
     const ObjRec<T> *objrecs; // n_objects records in slot order
     uint32_t tlas_depth, n_objects;
-    uint32_t tlas_mode, tlas_pad; // 0: tree, 1: flat scan + per-lane candidate list (<= 32 objects), 2: lockstep scan
+    uint32_t tlas_mode, tlas_pad; // 0: tree, 1: flat scan + per-lane candidate list (<= 32 objects)
     const ObjConst<T> *objects;
     // BLAS
     const BlasInfo *blas;
