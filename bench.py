@@ -44,6 +44,9 @@ PIXEL_BYTES = {  # compulsory bytes per pixel per launch of the streaming kernel
 }
 
 
+FUSED_TAIL = {"trace_gi": "shade2", "trace_di2": "compose"}  # k_trace_gi shades the hit; the last k_trace_di composes
+
+
 def trace_bytes(counters, stage, prec):
     i = 0 if prec == abi.F32 else 1
     c = counters
@@ -157,6 +160,9 @@ def roofline_of(res, prec, npix_window, spp):
         launches_per_frame = 1 if name == "primary" else spp
         bytes_per_launch = per_frame / launches_per_frame
         basis = "visit counters x reference record sizes (SURVEY.md 8(d))"
+        if name in FUSED_TAIL:  # the kernel also runs a streaming stage of the reference on the same pixels
+            bytes_per_launch += PIXEL_BYTES[FUSED_TAIL[name]][i] * npix_window
+            basis += f" + {FUSED_TAIL[name]} compulsory bytes/pixel (SURVEY.md 8(a))"
     else:
         bytes_per_launch = PIXEL_BYTES[name][i] * npix_window
         basis = "compulsory bytes/pixel x pixels (SURVEY.md 8(a))"

@@ -11,6 +11,16 @@
 #include "shade.hpp"
 #include "trace.hpp"
 
+// Waves per SIMD the traversal kernels are compiled for (VGPR budget = 512 / waves).  Traversal is latency-bound, so
+// the closest-hit kernels take a fifth wave at the price of a few spilled registers (measured on MI355X, Cornell 1080p:
+// k_trace_gi 235 -> 213 us per launch); the shadow-ray kernel loses more to its spills than it gains (129 -> 154 us).
+#ifndef LPRT_CLOSEST_WAVES
+#define LPRT_CLOSEST_WAVES 5
+#endif
+#ifndef LPRT_ANYHIT_WAVES
+#define LPRT_ANYHIT_WAVES 4
+#endif
+
 namespace lprt {
 
 template <typename T> LPRT_DEV V3<T> ld3(const T *p) { return mk3(p[0], p[1], p[2]); }
@@ -45,7 +55,7 @@ template <typename T> LPRT_DEV HitAttr<T> interpolate_hit(const SceneDev<T> &sc,
 
 // ---- G2: fill_gbuffer_in_cuda (cuda.hpp:950-1012) ---------------------------------------------------------
 template <typename T, bool COUNT>
-__global__ void __launch_bounds__(256) k_fill_gbuffer(SceneDev<T> sc, FrameDev<T> fb, Counters *counters) {
+__global__ void __launch_bounds__(256, LPRT_CLOSEST_WAVES) k_fill_gbuffer(SceneDev<T> sc, FrameDev<T> fb, Counters *counters) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     Cnt<COUNT> cnt;
     if (p < fb.win.npix()) {
@@ -424,7 +434,7 @@ struct ComposeArgs {
     uint32_t sample, spp;
 };
 template <typename T, bool FIRST, bool COMPOSE, bool COUNT>
-__global__ void __launch_bounds__(256) k_trace_di(SceneDev<T> sc, FrameDev<T> fb, ComposeArgs ca, Counters *counters) {
+__global__ void __launch_bounds__(256, LPRT_ANYHIT_WAVES) k_trace_di(SceneDev<T> sc, FrameDev<T> fb, ComposeArgs ca, Counters *counters) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t npix = fb.win.npix();
     Cnt<COUNT> cnt;
@@ -499,7 +509,7 @@ __global__ void __launch_bounds__(256) k_trace_di(SceneDev<T> sc, FrameDev<T> fb
 // The reference stores a PixelShaderInput record per pixel and launches shade<false,true> over it; nothing but the
 // traversal result is live here when the traversal ends, so the record stays in registers.
 template <typename T, bool COUNT>
-__global__ void __launch_bounds__(256) k_trace_gi(SceneDev<T> sc, FrameDev<T> fb, Counters *counters) {
+__global__ void __launch_bounds__(256, LPRT_CLOSEST_WAVES) k_trace_gi(SceneDev<T> sc, FrameDev<T> fb, Counters *counters) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     Cnt<COUNT> cnt;
     if (p < fb.win.npix()) {

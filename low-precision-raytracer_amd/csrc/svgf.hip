@@ -154,10 +154,16 @@ __global__ void __launch_bounds__(256) k_temporal_color(FrameDev<T> fb, T color_
 // geometric part of a tap's weight, shared by both lobes: h * w_z * w_n is NOT pre-multiplied because the
 // reference multiplies w_z * w_n (* w_l) first and h last
 template <typename T> LPRT_DEV void geo_weights(T depth_p, T depth_q, V2<T> grad, T dx, T dy, V3<T> n_p, V3<T> n_q, T &w_z, T &w_n) {
-    // exp(-abs(dz) / (SIGMA_Z * abs(dot(grad, dp) + EPS))): the unary minus makes the quotient a float
-    float num = -(float)tabs(depth_p - depth_q);
-    float den = (float)((T)1 * tabs(dot(grad, V2<T>{dx, dy}) + SvgfConst<T>::eps()));
-    w_z = cvt<T>(svgf_exp(svgf_div(num, den)));
+    // exp(-abs(dz) / (SIGMA_Z * abs(dot(grad, dp) + EPS))): the unary minus makes the quotient a float.
+    // Traced G-buffers carry depth 1 on every covered pixel (Q11), so dz is 0 for all taps of nearly every wave: then
+    // the quotient is -0 (the denominator is never 0: dot(grad, dp) is an integer multiple of the stride, EPS is not)
+    // and exp(-0) = 1 exactly.  The wave skips the reciprocal and the exponential when no lane has a depth step.
+    w_z = (T)1;
+    if (__builtin_amdgcn_ballot_w64(!(depth_p == depth_q))) {
+        float num = -(float)tabs(depth_p - depth_q);
+        float den = (float)((T)1 * tabs(dot(grad, V2<T>{dx, dy}) + SvgfConst<T>::eps()));
+        w_z = cvt<T>(svgf_exp(svgf_div(num, den)));
+    }
     w_n = cvt<T>(svgf_pow128((float)tmax((T)0, dot(n_p, n_q))));
 }
 
@@ -290,6 +296,10 @@ __global__ void __launch_bounds__(256) k_wavelet(FrameDev<T> fb, const V4<T> *in
     sg[1] = tsqrt(tdiv(sg[1], gw));
     // w_l = exp(-|l_p - l_q| / (4 sigma_l + eps)): the denominator is per pixel
     const float den_l[2] = {(float)(cvt<T>(4.f) * sg[0] + SvgfConst<T>::eps()), (float)(cvt<T>(4.f) * sg[1] + SvgfConst<T>::eps())};
+#ifndef LPRT_EXACT_SVGF_MATH
+    // the per-pixel reciprocal and the log2(e) of exp() leave the tap loop: w_l = exp2(-|dl| * (log2e / den))
+    const float k_l[2] = {__builtin_amdgcn_rcpf(den_l[0]) * 1.44269504088896340736f, __builtin_amdgcn_rcpf(den_l[1]) * 1.44269504088896340736f};
+#endif
     // 2. 5x5 a-trous taps, x outer / y inner as in the reference
     const V4<T> nd_p = s_nd[cy][cx];
     const V2<T> grad = fb.depth_gradient[p];
@@ -318,7 +328,11 @@ __global__ void __launch_bounds__(256) k_wavelet(FrameDev<T> fb, const V4<T> *in
 #pragma unroll
             for (int l = 0; l < 2; l++) {
                 float num = -(float)tabs(illum_p[l] - iq[l]);
+#ifdef LPRT_EXACT_SVGF_MATH
                 T w_l = cvt<T>(svgf_exp(svgf_div(num, den_l[l])));
+#else
+                T w_l = cvt<T>(__builtin_amdgcn_exp2f(num * k_l[l]));
+#endif
                 T hw = h * (wzn * w_l);
                 if (tfinite(hw)) {
                     const V4<T> cq = l == 0 ? s_c0[ly][lx] : s_c1[ly][lx];
