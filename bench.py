@@ -160,9 +160,11 @@ def roofline_of(res, prec, npix_window, spp):
         launches_per_frame = 1 if name == "primary" else spp
         bytes_per_launch = per_frame / launches_per_frame
         basis = "visit counters x reference record sizes (SURVEY.md 8(d))"
-        if name in FUSED_TAIL:  # the kernel also runs a streaming stage of the reference on the same pixels
-            bytes_per_launch += PIXEL_BYTES[FUSED_TAIL[name]][i] * npix_window
-            basis += f" + {FUSED_TAIL[name]} compulsory bytes/pixel (SURVEY.md 8(a))"
+        if name in FUSED_TAIL:  # the kernel also runs a streaming stage of the reference
+            # shade #2 only has work where a GI ray was cast; the composition touches every pixel
+            units = res["stage_counters"][name]["rays"] / launches_per_frame if name == "trace_gi" else npix_window
+            bytes_per_launch += PIXEL_BYTES[FUSED_TAIL[name]][i] * units
+            basis += f" + {FUSED_TAIL[name]} compulsory bytes (SURVEY.md 8(a))"
     else:
         bytes_per_launch = PIXEL_BYTES[name][i] * npix_window
         basis = "compulsory bytes/pixel x pixels (SURVEY.md 8(a))"

@@ -245,7 +245,11 @@ constexpr int WV_BX = 64, WV_BY = 4;
 template <typename T, int STRIDE>
 __global__ void __launch_bounds__(256) k_wavelet(FrameDev<T> fb, const V4<T> *in0, V4<T> *out0, const V4<T> *in1, V4<T> *out1) {
     constexpr int TW = WV_BX + 4 * STRIDE, TH = WV_BY + 4;
-    __shared__ V4<T> s_nd[TH][TW], s_c0[TH][TW], s_c1[TH][TW];
+    // fp32 at strides 8 and 16: four staged planes (56 B per texel) leave room for only 3 / 2 workgroups per CU, and
+    // the kernel is latency-bound; there the colour planes are read straight from L1/L2 (rows are still contiguous
+    // across the wave) and LDS keeps the 24 B per texel that both lobes share.
+    constexpr bool LDS_COLOR = sizeof(T) == 2 || STRIDE < 8;
+    __shared__ V4<T> s_nd[TH][TW], s_c0[LDS_COLOR ? TH : 1][LDS_COLOR ? TW : 1], s_c1[LDS_COLOR ? TH : 1][LDS_COLOR ? TW : 1];
     __shared__ V2<T> s_il[TH][TW];
     const int W = (int)fb.win.W, R = (int)fb.win.rows();
     const int tx = (int)(threadIdx.x % WV_BX), ty = (int)(threadIdx.x / WV_BX);
@@ -258,8 +262,10 @@ __global__ void __launch_bounds__(256) k_wavelet(FrameDev<T> fb, const V4<T> *in
         if (gx >= 0 && gx < W && gy >= 0 && gy < R) {
             const uint32_t q = (uint32_t)(gy * W + gx);
             s_nd[ly][lx] = fb.g_normal_depth[q];
-            s_c0[ly][lx] = in0[q];
-            s_c1[ly][lx] = in1[q];
+            if (LDS_COLOR) {
+                s_c0[ly][lx] = in0[q];
+                s_c1[ly][lx] = in1[q];
+            }
             s_il[ly][lx] = V2<T>{fb.lobe[0].illum[q], fb.lobe[1].illum[q]};
         }
     }
@@ -335,7 +341,7 @@ __global__ void __launch_bounds__(256) k_wavelet(FrameDev<T> fb, const V4<T> *in
 #endif
                 T hw = h * (wzn * w_l);
                 if (tfinite(hw)) {
-                    const V4<T> cq = l == 0 ? s_c0[ly][lx] : s_c1[ly][lx];
+                    const V4<T> cq = LDS_COLOR ? (l == 0 ? s_c0[ly][lx] : s_c1[ly][lx]) : in[l][(uint32_t)(qy * W + qx)];
                     if (tfinite(cq.w)) {
                         nvar[l] = nvar[l] + hw * hw * cq.w;
                         wv[l] = wv[l] + hw;
@@ -352,7 +358,7 @@ __global__ void __launch_bounds__(256) k_wavelet(FrameDev<T> fb, const V4<T> *in
     for (int l = 0; l < 2; l++) {
         T nv = tdiv(nvar[l], wv[l] * wv[l]);
         V3<T> nc = vdiv(ncol[l], wc[l]);
-        V4<T> centre = l == 0 ? s_c0[cy][cx] : s_c1[cy][cx];
+        V4<T> centre = LDS_COLOR ? (l == 0 ? s_c0[cy][cx] : s_c1[cy][cx]) : in[l][p];
         value_or(nc, xyz(centre));
         if (!tfinite(nv))
             nv = centre.w;
