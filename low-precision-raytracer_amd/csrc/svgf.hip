@@ -241,6 +241,9 @@ __global__ void __launch_bounds__(256) k_moments(FrameDev<T> fb, T moments_w) {
 // filter is a dense 5-row stencil, so the 8 lattice rows x (64 + 4s) columns it needs are staged in LDS once (every
 // load a full coalesced row segment) and the 25 taps x 4 planes become LDS reads — for every stride, including 8 and
 // 16 where a plain image tile would not fit.  Per thread: ~10-16 global loads instead of 125.
+#ifndef LPRT_WV_LDS_BELOW
+#define LPRT_WV_LDS_BELOW 8
+#endif
 constexpr int WV_BX = 64, WV_BY = 4;
 template <typename T, int STRIDE>
 __global__ void __launch_bounds__(256) k_wavelet(FrameDev<T> fb, const V4<T> *in0, V4<T> *out0, const V4<T> *in1, V4<T> *out1) {
@@ -248,7 +251,7 @@ __global__ void __launch_bounds__(256) k_wavelet(FrameDev<T> fb, const V4<T> *in
     // fp32 at strides 8 and 16: four staged planes (56 B per texel) leave room for only 3 / 2 workgroups per CU, and
     // the kernel is latency-bound; there the colour planes are read straight from L1/L2 (rows are still contiguous
     // across the wave) and LDS keeps the 24 B per texel that both lobes share.
-    constexpr bool LDS_COLOR = sizeof(T) == 2 || STRIDE < 8;
+    constexpr bool LDS_COLOR = sizeof(T) == 2 || STRIDE < LPRT_WV_LDS_BELOW;
     __shared__ V4<T> s_nd[TH][TW], s_c0[LDS_COLOR ? TH : 1][LDS_COLOR ? TW : 1], s_c1[LDS_COLOR ? TH : 1][LDS_COLOR ? TW : 1];
     __shared__ V2<T> s_il[TH][TW];
     const int W = (int)fb.win.W, R = (int)fb.win.rows();
