@@ -313,6 +313,10 @@ int lprt_reset_counters(lprt_ctx *ctx);
 
 /* Per-stage HIP-event timing (ms, accumulated since the last reset) and launch counts. */
 int lprt_enable_stage_timing(lprt_ctx *ctx, int enable);
+/* Only the stages whose bit (1u << lprt_stage_id) is set are bracketed by events; 0 turns timing off.  Two event
+ * records per launch cost about 4 us of stream time each on this stack, so a measurement that wants the frame rate
+ * AND one kernel's duration instruments that kernel only. */
+int lprt_set_stage_timing_mask(lprt_ctx *ctx, uint32_t stage_mask);
 int lprt_get_stage_times(lprt_ctx *ctx, float ms[LPRT_STAGE_COUNT], uint32_t launches[LPRT_STAGE_COUNT]);
 int lprt_reset_stage_times(lprt_ctx *ctx);
 

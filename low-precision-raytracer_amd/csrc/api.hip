@@ -113,7 +113,7 @@ struct CtxBase {
     }
     bool debug_sync = std::getenv("LPRT_DEBUG_SYNC") != nullptr;
     template <typename F> void stage(int id, F &&f) {
-        if (!timer.enabled && !debug_sync) {
+        if ((!timer.enabled || !(timer.mask & (1u << id))) && !debug_sync) {
             f();
             return;
         }
@@ -930,7 +930,16 @@ int lprt_output_device_ptr(lprt_ctx *ctx, void **ptr, size_t *bytes) {
     });
 }
 int lprt_enable_stage_timing(lprt_ctx *ctx, int enable) {
-    return guarded(ctx, [&](CtxBase &c) { c.timer.enabled = enable != 0; });
+    return guarded(ctx, [&](CtxBase &c) {
+        c.timer.enabled = enable != 0;
+        c.timer.mask = 0xffffffffu;
+    });
+}
+int lprt_set_stage_timing_mask(lprt_ctx *ctx, uint32_t stage_mask) {
+    return guarded(ctx, [&](CtxBase &c) {
+        c.timer.enabled = stage_mask != 0;
+        c.timer.mask = stage_mask;
+    });
 }
 int lprt_get_stage_times(lprt_ctx *ctx, float ms[LPRT_STAGE_COUNT], uint32_t launches[LPRT_STAGE_COUNT]) {
     return guarded(ctx, [&](CtxBase &c) {

@@ -49,6 +49,7 @@ struct DevBuf {
 
 struct StageTimer {
     bool enabled = false;
+    uint32_t mask = 0xffffffffu; // bit s set: stage s is bracketed by events
     float ms[LPRT_STAGE_COUNT] = {};
     uint32_t launches[LPRT_STAGE_COUNT] = {};
     struct Pending {

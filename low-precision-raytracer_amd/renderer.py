@@ -52,6 +52,7 @@ SYMBOLS = [
     ("lprt_debug_sample_texture", C.c_int, [_P, C.c_uint32, _P, C.c_uint32, _P]),
     ("lprt_debug_rng_states", C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_uint32, _P]),
     ("lprt_enable_stage_timing", C.c_int, [_P, C.c_int]),
+    ("lprt_set_stage_timing_mask", C.c_int, [_P, C.c_uint32]),
     ("lprt_get_stage_times", C.c_int, [_P, _P, _P]),
     ("lprt_reset_stage_times", C.c_int, [_P]),
     ("lprt_get_blas_info", C.c_int, [_P, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
@@ -239,6 +240,13 @@ class Renderer:
 
     def enable_stage_timing(self, on=True):
         self._check(self.L.lprt_enable_stage_timing(self.h, int(on)), "lprt_enable_stage_timing")
+
+    def set_stage_timing_mask(self, stages):
+        """Time only the named stages (an iterable of abi.STAGES names); empty turns timing off."""
+        mask = 0
+        for s in stages:
+            mask |= 1 << abi.STAGES.index(s)
+        self._check(self.L.lprt_set_stage_timing_mask(self.h, mask), "lprt_set_stage_timing_mask")
 
     def stage_times(self):
         ms = (C.c_float * len(abi.STAGES))()
