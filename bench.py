@@ -157,6 +157,22 @@ def measure(prec, sc, W, H, spp, steps, warmup, rank, world, device, stage_timin
     return res
 
 
+def pmc_traffic(kernel, prec):
+    """HBM bytes per launch of `kernel` from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    separate passes over this same command, FETCH_SIZE doubled as the gfx950 guide prescribes: tools/collect_profiles.sh,
+    tools/summarize_profiles.py).  Counters cannot be read from inside the timed process, so this is the last
+    collected value for the same workload, or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+        e = d.get(f"{kernel}[{'f32' if prec == abi.F32 else 'f16'}]")
+        if e and "hbm_bytes_per_launch" in e:
+            return e["hbm_bytes_per_launch"], "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+    except (OSError, ValueError):
+        pass
+    return None, None
+
+
 def roofline_of(res, prec, npix_window, spp):
     """Dominant kernel family (largest HIP-event time over the calibration frames) against the HBM roof; its launch
     duration is the live average over the timed region, where it is the only instrumented stage."""
@@ -185,8 +201,10 @@ def roofline_of(res, prec, npix_window, spp):
         bytes_per_launch = PIXEL_BYTES[name][i] * npix_window
         basis = "compulsory bytes/pixel x pixels (SURVEY.md 8(a))"
     achieved = bytes_per_launch / avg_s
-    return {"bound": "hbm", "kernel": abi.STAGE_KERNELS.get(name, name), "stage": name, "achieved": achieved / 1e9,
-            "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+    kernel = abi.STAGE_KERNELS.get(name, name)
+    traffic, traffic_src = pmc_traffic(kernel, prec)
+    return {"bound": "hbm", "kernel": kernel, "stage": name, "achieved": achieved / 1e9,
+            "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
             "avg_launch_us": avg_s * 1e6, "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
             "basis": basis}
 
