@@ -730,6 +730,15 @@ void lprt_destroy(lprt_ctx *ctx) {
         (void)hipSetDevice(ctx->impl->device);
         if (ctx->impl->stream)
             (void)hipStreamSynchronize(ctx->impl->stream);
+        (void)hipDeviceSynchronize(); // nothing of this context may be in flight on any stream while its memory goes away
+        for (auto &p : ctx->impl->timer.pending) {
+            (void)hipEventDestroy(p.a);
+            (void)hipEventDestroy(p.b);
+        }
+        for (hipEvent_t e : ctx->impl->timer.pool)
+            (void)hipEventDestroy(e);
+        ctx->impl->timer.pending.clear();
+        ctx->impl->timer.pool.clear();
         hipStream_t s = ctx->impl->own_stream ? ctx->impl->stream : nullptr;
         ctx->impl.reset();
         if (s)
