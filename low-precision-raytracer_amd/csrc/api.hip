@@ -201,7 +201,6 @@ template <typename T> struct Impl : CtxBase {
         fb.gi_multiplier1 = carve<V4<T>>(off, n);
         fb.intensity0 = carve<V4<T>>(off, n);
         fb.intensity1 = carve<V4<T>>(off, n);
-        fb.view_direction = carve<V4<T>>(off, n);
         fb.skips = carve<uint2>(off, n);
         fb.gi_source = nullptr;
         fb.gi_direction = carve<V4<T>>(off, n);
@@ -319,7 +318,7 @@ template <typename T> struct Impl : CtxBase {
                 fb.rng_state = d_rng_planes.as<uint32_t>() + (size_t)next_plane * 5 * npix;
                 d_b = seed_d[next_plane++];
             }
-            stage(LPRT_STAGE_SHADE1, [&] { launch_shade<T>(stream, sc, fb, !fs.gi_on, d_b); });
+            stage(LPRT_STAGE_SHADE1, [&] { launch_shade<T>(stream, sc, fb, !fs.gi_on, d_b, s); });
             stage(LPRT_STAGE_TRACE_DI1, [&] {
                 launch_trace_di<T>(stream, sc, fb, true, fs.gi_on != 0, fs.add_direct_out != 0, s, spp, stage_counters(LPRT_STAGE_TRACE_DI1));
             });

@@ -87,7 +87,6 @@ template <typename T> struct FrameDev {
     V4<T> *gi_multiplier;   // gi_material_multiplier[0] (w: unused)
     V4<T> *gi_multiplier1;  // gi_material_multiplier[1] — never read by the reference, kept for completeness
     V4<T> *intensity0, *intensity1;
-    V4<T> *view_direction;
     uint2 *skips;
     V4<T> *gi_source, *gi_direction; // TraceGICommand (x/y implicit: the pixel itself)
     uint8_t *gi_valid;

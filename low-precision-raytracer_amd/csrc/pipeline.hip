@@ -206,7 +206,7 @@ template <typename T> struct ShadeIn {
 };
 
 template <typename T, bool FIRST, bool NO_GI>
-LPRT_DEV void shade_and_store(const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t p, uint32_t rng_d, const ShadeIn<T> &in) {
+LPRT_DEV void shade_and_store(const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t p, uint32_t rng_d, const ShadeIn<T> &in, bool first_sample) {
     const uint32_t npix = fb.win.npix();
     const uint32_t x = p % fb.win.W, y = fb.win.row_begin + p / fb.win.W;
     const T zero = (T)0, one = (T)1;
@@ -231,7 +231,7 @@ LPRT_DEV void shade_and_store(const SceneDev<T> &sc, const FrameDev<T> &fb, uint
         if (FIRST)
             view_dir = neg(primary_ray_direction(sc, fb.win.W, fb.win.H, x, y));
         else
-            view_dir = xyz(fb.view_direction[p]);
+            view_dir = neg(xyz(fb.gi_direction[p])); // view_direction of round 1 = -(GI direction) (cuda.hpp:1985)
         if (dot(view_dir, normal) < zero) {
             if (material.double_sided)
                 normal = neg(normal);
@@ -241,7 +241,7 @@ LPRT_DEV void shade_and_store(const SceneDev<T> &sc, const FrameDev<T> &fb, uint
     }
     // Outputs are collected in registers and written by one unconditional store sequence at the end (see the
     // note in k_fill_gbuffer about stores in both arms of a branch).
-    V4<T> o_intensity = zero4, o_albedo = zero4, o_mult = zero4, o_gidir = zero4, o_view = zero4;
+    V4<T> o_intensity = zero4, o_albedo = zero4, o_mult = zero4, o_gidir = zero4;
     uint2 o_skip = make_uint2(0xffffffffu, 0u);
     uint32_t o_gi_valid = 0, mask = 0;
     if (live) {
@@ -328,8 +328,6 @@ LPRT_DEV void shade_and_store(const SceneDev<T> &sc, const FrameDev<T> &fb, uint
             }
             o_gi_valid = 1;
             o_gidir = mk4(dir.x, dir.y, dir.z, zero);
-            V3<T> nd = neg(dir);
-            o_view = mk4(nd.x, nd.y, nd.z, zero);
             o_mult = mk4(mult.x, mult.y, mult.z, zero);
             o_intensity = mk4(emission.x, emission.y, emission.z, zero);
         } else {
@@ -377,7 +375,7 @@ LPRT_DEV void shade_and_store(const SceneDev<T> &sc, const FrameDev<T> &fb, uint
     }
     if (sky_pixel && sc.sky_valid) {
         // the reference parks this in di_intensity[4p + 0]; accumulate_di_light then adds 0 + sky + 0 + 0 + 0 to a cleared pixel
-        V3<T> dir = FIRST ? primary_ray_direction(sc, fb.win.W, fb.win.H, x, y) : neg(normalized(xyz(fb.view_direction[p])));
+        V3<T> dir = FIRST ? primary_ray_direction(sc, fb.win.W, fb.win.H, x, y) : neg(normalized(neg(xyz(fb.gi_direction[p]))));
         V3<T> sky = sample_skybox(sc, dir);
         o_intensity = mk4(sky.x, sky.y, sky.z, zero);
     }
@@ -387,16 +385,16 @@ LPRT_DEV void shade_and_store(const SceneDev<T> &sc, const FrameDev<T> &fb, uint
     if (!FIRST) // the shadow rays of round 1 start at the GI hit
         fb.sc_position[p] = live ? mk4(position.x, position.y, position.z, zero) : zero4;
     if (FIRST) {
-        fb.albedo[p] = o_albedo;
+        if (first_sample) // the albedo does not depend on the sample
+            fb.albedo[p] = o_albedo;
         fb.gi_valid[p] = (uint8_t)o_gi_valid; // DEVIATION Q13: untouched GI commands are invalid
         fb.gi_multiplier[p] = o_mult;
         fb.gi_direction[p] = o_gidir;
-        fb.view_direction[p] = o_view;
     }
 }
 
 template <typename T, bool NO_GI>
-__global__ void __launch_bounds__(256) k_shade(SceneDev<T> sc, FrameDev<T> fb, uint32_t rng_d) {
+__global__ void __launch_bounds__(256) k_shade(SceneDev<T> sc, FrameDev<T> fb, uint32_t rng_d, uint32_t sample) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= fb.win.npix())
         return;
@@ -423,7 +421,7 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev<T> sc, FrameDev<T> fb, u
         in.material = sc.materials[oc->materialid];
         in.objectid = oc->objectid;
     }
-    shade_and_store<T, true, NO_GI>(sc, fb, p, rng_d, in);
+    shade_and_store<T, true, NO_GI>(sc, fb, p, rng_d, in, sample == 0u);
 }
 
 // ---- TD + A (+ W): trace_di_light + accumulate_di_light (cuda.hpp:2058-2081, 2143-2159); the LAST round of a sample
@@ -540,7 +538,7 @@ __global__ void __launch_bounds__(256, LPRT_CLOSEST_WAVES) k_trace_gi(SceneDev<T
                 in.sky_pixel = true; // SKYBOX
             }
         }
-        shade_and_store<T, false, true>(sc, fb, p, 0u, in);
+        shade_and_store<T, false, true>(sc, fb, p, 0u, in, false);
     }
     flush_counters<COUNT>(cnt, counters);
 }
@@ -557,12 +555,12 @@ template <typename T> void launch_fill_gbuffer(hipStream_t st, const SceneDev<T>
 template <typename T> void launch_temporal_map(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, uint32_t rng_d) {
     hipLaunchKernelGGL(k_temporal_map<T>, grid_for(fb.win.npix()), dim3(256), 0, st, sc, fb, first ? 1 : 0, rng_d);
 }
-template <typename T> void launch_shade(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool no_gi, uint32_t rng_d) {
+template <typename T> void launch_shade(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool no_gi, uint32_t rng_d, uint32_t sample) {
     dim3 g = grid_for(fb.win.npix()), b(256);
     if (!no_gi)
-        hipLaunchKernelGGL((k_shade<T, false>), g, b, 0, st, sc, fb, rng_d);
+        hipLaunchKernelGGL((k_shade<T, false>), g, b, 0, st, sc, fb, rng_d, sample);
     else
-        hipLaunchKernelGGL((k_shade<T, true>), g, b, 0, st, sc, fb, rng_d);
+        hipLaunchKernelGGL((k_shade<T, true>), g, b, 0, st, sc, fb, rng_d, sample);
 }
 // first: round 0 (composes when GI is off: it is the only round), else round 1 (always composes)
 template <typename T>
@@ -597,7 +595,7 @@ template <typename T> void launch_trace_gi(hipStream_t st, const SceneDev<T> &sc
 #define INST(T)                                                                                                        \
     template void launch_fill_gbuffer<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, Counters *);          \
     template void launch_temporal_map<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, uint32_t);      \
-    template void launch_shade<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, uint32_t);             \
+    template void launch_shade<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, uint32_t, uint32_t);   \
     template void launch_trace_di<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, bool, bool, uint32_t, uint32_t, Counters *); \
     template void launch_trace_gi<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, Counters *);
 INST(float)
