@@ -376,3 +376,13 @@ def test_cpp_host_over_compat_header_renders_the_same_frames(cornell, tmp_path, 
         r.set_scene(cornell)
         r.render(abi.default_settings(spp=2))
     assert np.array_equal(got, r.read("OUTPUT"), equal_nan=True)
+
+
+@pytest.mark.parametrize("prec", [abi.F32, abi.F16])
+@pytest.mark.parametrize("W,H", [(67, 131), (161, 9)])
+def test_odd_frame_sizes_hit_every_tile_edge(cornell, W, H, prec):
+    """Widths / heights that are multiples of nothing: partial LDS tiles in k_temporal_color (32x8), k_wavelet (64x4
+    lattice tiles, strides up to 16 > the frame height) and partial last workgroups everywhere; two frames."""
+    r, o = render_pair(cornell, W, H, prec, frames=2, spp=2)
+    for name in ("COLOR_INPROGRESS", "MUL_GI_COLORED", "MUL_GI_WHITE", "OUTPUT"):
+        assert rel_l2(r.read(name), o.read(name)) < TOL[prec], name
