@@ -198,11 +198,9 @@ template <typename T> struct Impl : CtxBase {
         fb.g_objid = carve<uint32_t>(off, n);
         fb.g_offset = carve<uint32_t>(off, n);
         fb.gi_multiplier = carve<V4<T>>(off, n);
-        fb.gi_multiplier1 = carve<V4<T>>(off, n);
         fb.intensity0 = carve<V4<T>>(off, n);
         fb.intensity1 = carve<V4<T>>(off, n);
         fb.skips = carve<uint2>(off, n);
-        fb.gi_source = nullptr;
         fb.gi_direction = carve<V4<T>>(off, n);
         fb.gi_valid = carve<uint8_t>(off, n);
         fb.lc_dir_maxt = carve<V4<T>>(off, n * LPRT_MAX_DIRECT_LIGHT);

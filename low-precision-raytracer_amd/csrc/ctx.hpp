@@ -85,10 +85,9 @@ template <typename T> struct FrameDev {
     uint32_t *g_color, *g_objid, *g_offset;
     // shade <-> trace hand-over
     V4<T> *gi_multiplier;   // gi_material_multiplier[0] (w: unused)
-    V4<T> *gi_multiplier1;  // gi_material_multiplier[1] — never read by the reference, kept for completeness
     V4<T> *intensity0, *intensity1;
     uint2 *skips;
-    V4<T> *gi_source, *gi_direction; // TraceGICommand (x/y implicit: the pixel itself)
+    V4<T> *gi_direction;    // TraceGICommand (x/y implicit: the pixel itself; the source is the G-buffer position)
     uint8_t *gi_valid;
     // light commands, SoA by slot: slot s of pixel p at [s * npix + p]
     V4<T> *lc_dir_maxt;     // direction.xyz, maximum_t
