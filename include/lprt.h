@@ -189,7 +189,8 @@ typedef enum {
     LPRT_BUF_RAW_GI_COLORED = 14,  /* [rows][W][3] */
     LPRT_BUF_RAW_GI_WHITE = 15,    /* [rows][W][3] */
     LPRT_BUF_RAW_COLOR = 16,       /* [rows][W][3] color_inprogress before add_denoised_color */
-    LPRT_BUF_COUNT = 17
+    LPRT_BUF_GI_DIRECTION = 17,    /* [rows][W][4] last sample's GI ray direction (TraceGICommand), w = 1 where a ray was cast */
+    LPRT_BUF_COUNT = 18
 } lprt_buffer_id;
 
 /* Per-kernel GPU time (HIP events on the context's stream) and work counters; one id per kernel family.

@@ -72,9 +72,9 @@ class Counters(C.Structure):
 
 BUF = dict(COLOR_INPROGRESS=0, MUL_GI_COLORED=1, MUL_GI_WHITE=2, INTENSITY0=3, INTENSITY1=4, ALBEDO=5, OUTPUT=6,
            G_POSITION=7, G_NORMAL_DEPTH=8, G_TANGENT=9, G_UV0UV1=10, G_COLOR=11, G_OBJID=12, G_OFFSET=13,
-           RAW_GI_COLORED=14, RAW_GI_WHITE=15, RAW_COLOR=16)
+           RAW_GI_COLORED=14, RAW_GI_WHITE=15, RAW_COLOR=16, GI_DIRECTION=17)
 BUF_CHANNELS = {0: 3, 1: 3, 2: 3, 3: 3, 4: 3, 5: 3, 6: 4, 7: 4, 8: 4, 9: 4, 10: 4, 11: 4, 12: 1, 13: 1, 14: 3, 15: 3,
-                16: 3}
+                16: 3, 17: 4}
 STAGES = ["build_blas", "build_tlas", "primary", "temporal_map", "rng", "shade1", "trace_di1", "trace_gi", "shade2",
           "trace_di2", "compose", "svgf_gradient", "svgf_temporal", "svgf_moments", "svgf_wavelet", "finalize", "backup"]
 # device kernel behind each stage id (the names rocprofv3 --kernel-trace reports)

@@ -386,6 +386,7 @@ template <typename T> struct Impl : CtxBase {
         case LPRT_BUF_G_OBJID: u32 = fb.g_objid; ch = 1; break;
         case LPRT_BUF_G_OFFSET: u32 = fb.g_offset; ch = 1; break;
         case LPRT_BUF_OUTPUT: ch = 4; break;
+        case LPRT_BUF_GI_DIRECTION: v4 = fb.gi_direction; ch = 4; break;
         default: throw std::string("unknown buffer id");
         }
         if (n_floats != (size_t)n * ch)

@@ -327,7 +327,7 @@ LPRT_DEV void shade_and_store(const SceneDev<T> &sc, const FrameDev<T> &fb, uint
                     mult = m * get_brdf(b, color);
             }
             o_gi_valid = 1;
-            o_gidir = mk4(dir.x, dir.y, dir.z, zero);
+            o_gidir = mk4(dir.x, dir.y, dir.z, one); // w = 1: a ray is cast (read-back only)
             o_mult = mk4(mult.x, mult.y, mult.z, zero);
             o_intensity = mk4(emission.x, emission.y, emission.z, zero);
         } else {

@@ -28,9 +28,51 @@ template <typename T> LPRT_DEV RayT<T> transform_ray(const RayT<T> &r, const M4<
 template <typename T> struct RaySlab {
     V3<T> o;
     float ix, iy, iz;
+    uint32_t par; // bit k: the ray does not move along axis k (1/d is not finite)
 };
 template <typename T> LPRT_DEV RaySlab<T> make_slab(const RayT<T> &r) {
-    return {r.o, 1.0f / (float)r.d.x, 1.0f / (float)r.d.y, 1.0f / (float)r.d.z};
+    RaySlab<T> s{r.o, 1.0f / (float)r.d.x, 1.0f / (float)r.d.y, 1.0f / (float)r.d.z, 0u};
+    s.par = (__builtin_isfinite(s.ix) ? 0u : 1u) | (__builtin_isfinite(s.iy) ? 0u : 2u) | (__builtin_isfinite(s.iz) ? 0u : 4u);
+    return s;
+}
+// A ray that does not move along an axis can only hit what its origin lies inside of on that axis.  The reference's slab
+// test IGNORES such an axis (below), which is conservative and costs nothing as long as those rays are not cast; but
+// they are: Box-Muller returns the pair (0, 0) when its uniform rounds to 1.0f (2^-25 of the draws), so every few
+// frames one GI ray is exactly axis-aligned, passes every box in front of it and walks the whole BLAS (131 k nodes and
+// 91 k triangle tests for ONE ray of the 262 k-triangle atrium: 136 ms).  Boxes whose extent on a stationary axis does
+// not contain the origin, with a margin far wider than the triangle test's tolerance zones (1/8 of the box + 2^-7
+// relative), are rejected here; the triangles the ray can hit are all still visited, so the result is unchanged.
+template <typename T> LPRT_DEV bool stationary_axis_outside(float o, T lo, T hi) {
+    const float l = (float)lo, h = (float)hi;
+    const float m = (h - l) * 0.125f + (__builtin_fabsf(l) + __builtin_fabsf(h)) * 0.0078125f + 1e-6f;
+    return o < l - m || o > h + m;
+}
+// Half precision only: an entry/exit parameter beyond 65504 is +-inf in half, and the reference then ignores the axis
+// like a stationary one.  That happens to every ray with a direction component below ~5e-4 against boxes more than a
+// few units away (about one GI ray in a thousand in the 30 m atrium), each of which then walks a whole slab of the
+// tree — or all of it when two axes drop out (100+ ms per frame).  The dropped axes are re-evaluated in float, where
+// nothing overflows, against the box widened by the same margin as above; a box the ray misses even so cannot contain
+// a triangle the (toleranced) triangle test would accept.
+template <typename T>
+LPRT_DEV bool overflowed_axes_miss(const T *lo, const T *hi, const RaySlab<T> &rs, bool ok0, bool ok1, bool ok2, float tn, float tf) {
+    const float o[3] = {(float)rs.o.x, (float)rs.o.y, (float)rs.o.z}, inv[3] = {rs.ix, rs.iy, rs.iz};
+    const bool ok[3] = {ok0, ok1, ok2};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (ok[k] || ((rs.par >> k) & 1u))
+            continue; // kept by the half test, or stationary (handled by stationary_reject)
+        const float l = (float)lo[k], h = (float)hi[k];
+        const float m = (h - l) * 0.125f + (__builtin_fabsf(l) + __builtin_fabsf(h)) * 0.0078125f + 1e-6f;
+        const float ta = (l - m - o[k]) * inv[k], tb = (h + m - o[k]) * inv[k];
+        tn = __builtin_fmaxf(tn, __builtin_fminf(ta, tb));
+        tf = __builtin_fminf(tf, __builtin_fmaxf(ta, tb));
+    }
+    return tf < -1e-3f || tn > tf * 1.002f + 0.02f;
+}
+template <typename T> LPRT_DEV bool stationary_reject(const T *lo, const T *hi, const RaySlab<T> &rs) {
+    return ((rs.par & 1u) && stationary_axis_outside((float)rs.o.x, lo[0], hi[0])) ||
+           ((rs.par & 2u) && stationary_axis_outside((float)rs.o.y, lo[1], hi[1])) ||
+           ((rs.par & 4u) && stationary_axis_outside((float)rs.o.z, lo[2], hi[2]));
 }
 template <typename T> LPRT_DEV T slab_t(T bound, T origin, float inv) {
     // (bound - origin) / d with the quotient formed as a product with the f32 reciprocal and rounded to T
@@ -40,7 +82,7 @@ template <typename T> LPRT_DEV T slab_t(T bound, T origin, float inv) {
 // ray_aabb_intersection_scene / _object (cuda.hpp:70-149). Axes whose entry/exit is not finite are ignored
 // (parallel rays), as in the reference; entry = max over the remaining axes, exit = min (the reference's sequential
 // update computes exactly these extrema).
-template <typename T, bool SCENE> LPRT_DEV bool slab_test(const T *lo, const T *hi, const RaySlab<T> &rs, T &tmn, T &tmx) {
+template <typename T, bool SCENE, bool PAR = false> LPRT_DEV bool slab_test(const T *lo, const T *hi, const RaySlab<T> &rs, T &tmn, T &tmx) {
     const T a0 = slab_t(lo[0], rs.o.x, rs.ix), b0 = slab_t(hi[0], rs.o.x, rs.ix);
     const T a1 = slab_t(lo[1], rs.o.y, rs.iy), b1 = slab_t(hi[1], rs.o.y, rs.iy);
     const T a2 = slab_t(lo[2], rs.o.z, rs.iz), b2 = slab_t(hi[2], rs.o.z, rs.iz);
@@ -54,6 +96,10 @@ template <typename T, bool SCENE> LPRT_DEV bool slab_test(const T *lo, const T *
     tmn = t1max;
     tmx = t2min;
     if (!(ok0 | ok1 | ok2))
+        return false;
+    if (PAR && stationary_reject(lo, hi, rs)) // only in the instantiation that rays with a stationary axis take
+        return false;
+    if (Num<T>::is_half && !(ok0 & ok1 & ok2) && overflowed_axes_miss(lo, hi, rs, ok0, ok1, ok2, (float)t1max, (float)t2min))
         return false;
     if (SCENE) {
         T s = t2min + cvt<T>(0.02f);
@@ -185,7 +231,7 @@ LPRT_DEV void leaf_range_dev(uint32_t k, uint32_t D, uint32_t n, uint32_t &l, ui
 }
 
 // ---- T4: BLAS traversal (replaces search_intersection_in_object, cuda.hpp:415-504) -----------------
-template <typename T, bool ANY, bool COUNT>
+template <typename T, bool ANY, bool COUNT, bool PAR>
 LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, const RaySlab<T> &rs, const ObjRec<T> &ob, uint32_t skip_vao,
                             uint32_t skip_off, Isect<T> &is, T min_distance, T max_distance, Cnt<COUNT> &cnt) {
     if (COUNT)
@@ -195,7 +241,7 @@ LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, const Ray
     T tmn, tmx;
     if (COUNT)
         cnt.blas_nodes++;
-    if (!(slab_test<T, false>(ob.root_lo, ob.root_hi, rs, tmn, tmx) && tmn < is.t && tmn < max_distance && tmx > min_distance))
+    if (!(slab_test<T, false, PAR>(ob.root_lo, ob.root_hi, rs, tmn, tmx) && tmn < is.t && tmn < max_distance && tmx > min_distance))
         return;
     const InnerNode<T> *inner = sc.blas_inner + ob.inner_base;
     const uint32_t D = ob.depth;
@@ -223,8 +269,8 @@ LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, const Ray
             if (COUNT)
                 cnt.blas_nodes += 2;
             T n0, x0, n1, x1;
-            bool h0 = slab_test<T, false>(nd.lo0, nd.hi0, rs, n0, x0) && n0 < is.t && n0 < max_distance && x0 > min_distance;
-            bool h1 = slab_test<T, false>(nd.lo1, nd.hi1, rs, n1, x1) && n1 < is.t && n1 < max_distance && x1 > min_distance;
+            bool h0 = slab_test<T, false, PAR>(nd.lo0, nd.hi0, rs, n0, x0) && n0 < is.t && n0 < max_distance && x0 > min_distance;
+            bool h1 = slab_test<T, false, PAR>(nd.lo1, nd.hi1, rs, n1, x1) && n1 < is.t && n1 < max_distance && x1 > min_distance;
             if (h0 | h1) {
                 uint32_t first = (h0 && (!h1 || n0 <= n1)) ? 0u : 1u;
                 if (h0 & h1)
@@ -293,6 +339,13 @@ LPRT_DEV Isect<T> cast_ray(const SceneDev<T> &sc, const RayT<T> &ray, uint32_t s
             if (slab_test<T, true>(ob->lo, ob->hi, rs, tmn, tmx) && tmn < max_distance && tmx > min_distance)
                 cand |= 1u << k;
         }
+        if (rs.par) // a stationary axis: drop the world boxes the origin is not inside of on that axis (see make_slab)
+            for (uint32_t k = 0; k < sc.n_objects; k++)
+                if ((cand >> k) & 1u) {
+                    const ObjRec<T> *ob = sc.objrecs + k;
+                    if (stationary_reject(ob->lo, ob->hi, rs))
+                        cand &= ~(1u << k);
+                }
         while (cand) {
             const uint32_t k = (uint32_t)__builtin_ctz(cand);
             cand &= cand - 1u;
@@ -301,7 +354,10 @@ LPRT_DEV Isect<T> cast_ray(const SceneDev<T> &sc, const RayT<T> &ray, uint32_t s
             // (x*1 + y*0 + z*0 is exact), and a wave mixing walls and boxes does not run the BLAS walk twice
             const RayT<T> lr = transform_ray(ray, ob.W2L);
             const RaySlab<T> lrs = make_slab(lr);
-            traverse_blas<T, ANY, COUNT>(sc, lr, lrs, ob, skip_vao, skip_off, is, min_distance, max_distance, cnt);
+            if (lrs.par) // rare: the instantiation whose box tests also check the stationary axes
+                traverse_blas<T, ANY, COUNT, true>(sc, lr, lrs, ob, skip_vao, skip_off, is, min_distance, max_distance, cnt);
+            else
+                traverse_blas<T, ANY, COUNT, false>(sc, lr, lrs, ob, skip_vao, skip_off, is, min_distance, max_distance, cnt);
             if (ANY && is.hit)
                 return is;
         }
@@ -342,7 +398,10 @@ LPRT_DEV Isect<T> cast_ray(const SceneDev<T> &sc, const RayT<T> &ray, uint32_t s
                     const ObjRec<T> obv = *ob;
                     const RayT<T> lr = transform_ray(ray, obv.W2L);
                     const RaySlab<T> lrs = make_slab(lr);
-                    traverse_blas<T, ANY, COUNT>(sc, lr, lrs, obv, skip_vao, skip_off, is, min_distance, max_distance, cnt);
+                    if (lrs.par)
+                        traverse_blas<T, ANY, COUNT, true>(sc, lr, lrs, obv, skip_vao, skip_off, is, min_distance, max_distance, cnt);
+                    else
+                        traverse_blas<T, ANY, COUNT, false>(sc, lr, lrs, obv, skip_vao, skip_off, is, min_distance, max_distance, cnt);
                     if (ANY && is.hit)
                         return is;
                 }

@@ -185,3 +185,43 @@ def test_rng_states_match_curand_restatement():
                 want = np.zeros(6, dtype=np.uint32)
                 L.orc_xorwow_state(seed, first + i, want.ctypes.data_as(C.c_void_p))
                 assert np.array_equal(got[i], want), (seed, first + i)
+
+
+@pytest.mark.parametrize("prec", [abi.F32, abi.F16])
+def test_stationary_and_near_stationary_axes_do_not_walk_the_whole_tree(sponza, prec):
+    """Rays that do not move along one or two axes (Box-Muller hands shade() an exactly axis-aligned GI direction every few
+    frames) and, in half precision, rays whose slab parameters overflow 65504: the reference ignores those axes, so such
+    a ray passes every box in front of it.  The product rejects boxes the ray cannot reach (trace.hpp: stationary_reject,
+    overflowed_axes_miss) — same hits, a bounded walk."""
+    rng = np.random.default_rng(3)
+    n = 512
+    rays = np.zeros(n, dtype=abi.RAY_DTYPE)
+    lo, hi = sponza.aabbs[:, :3].min(axis=0) + 0.5, sponza.aabbs[:, 3:].max(axis=0) - 0.5
+    rays["source"] = rng.uniform(lo, hi, size=(n, 3)).astype(np.float32)
+    d = np.zeros((n, 3), dtype=np.float32)
+    axis = rng.integers(0, 3, size=n)
+    d[np.arange(n), axis] = rng.choice([-1.0, 1.0], size=n)
+    tiny = rng.normal(size=(n, 3)).astype(np.float32) * np.float32(1e-5)  # second half: almost axis-aligned
+    d[n // 2:] += tiny[n // 2:]
+    d[n // 2:] /= np.linalg.norm(d[n // 2:], axis=1, keepdims=True)
+    d[:8] *= np.float32(-0.0) + 1  # keep a few signed zeros: (-0, -0, -1) is what shade() produced
+    rays["direction"] = d
+    rays["min_distance"] = 1e-4 if prec == abi.F32 else 0.1
+    rays["max_distance"] = 1e5
+    rays["skip_vao"] = 0xFFFFFFFF
+    o = Oracle(16, 16, prec)
+    o.load_scene(sponza)
+    r = lprt_amd.Renderer(16, 16, prec)
+    r.load_scene(sponza)
+    r.enable_counters(True)
+    for any_hit in (False, True):
+        r.reset_counters()
+        hg, ho = r.trace(rays, any_hit), o.trace(rays, any_hit)
+        c = r.counters()
+        assert c["blas_node_visits"] / n < 400, c   # ~85 for a random ray; 131 k for an axis-aligned one before
+        if prec == abi.F32:
+            compare_hits(ho, hg, any_hit, 0.02)
+        else:
+            assert (ho["hit"] != hg["hit"]).mean() < 0.02
+            same = (ho["hit"] == 1) & (hg["hit"] == 1) & (ho["inobject_offset"] == hg["inobject_offset"])
+            assert same.sum() > 0.9 * ((ho["hit"] == 1) & (hg["hit"] == 1)).sum() or any_hit
