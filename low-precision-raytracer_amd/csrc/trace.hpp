@@ -97,10 +97,12 @@ template <typename T, bool SCENE, bool PAR = false> LPRT_DEV bool slab_test(cons
     tmx = t2min;
     if (!(ok0 | ok1 | ok2))
         return false;
+#ifndef LPRT_NO_AXIS_REJECT // A/B knob: the reference's plain test
     if (PAR && stationary_reject(lo, hi, rs)) // only in the instantiation that rays with a stationary axis take
         return false;
     if (Num<T>::is_half && !(ok0 & ok1 & ok2) && overflowed_axes_miss(lo, hi, rs, ok0, ok1, ok2, (float)t1max, (float)t2min))
         return false;
+#endif
     if (SCENE) {
         T s = t2min + cvt<T>(0.02f);
         return t1max <= s && 0.0f <= (float)s;

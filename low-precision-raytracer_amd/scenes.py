@@ -593,3 +593,28 @@ def write_blob(sc, width, height, path):
         f.write(bytes(cam))
         f.write(w2c.tobytes())
     return path
+
+
+def instanced_field(n_instances=150, seed=5):
+    """Many instances of a few small meshes (more than the 32 the flat TLAS scan handles): exercises the TLAS tree
+    walk, repeated BLASes under different transforms and several materials."""
+    rng = np.random.default_rng(seed)
+    meshes = [unit_cube(), fluted_column(0.3, 1.0, 8, 3), quad_grid((-0.5, 0, -0.5), (1, 0, 0), (0, 0, 1), 2, 2)]
+    materials = [dict(color=tuple(rng.uniform(0.2, 0.9, 3)), metallic=float(rng.choice([0.0, 1.0])),
+                      roughness=float(rng.choice([0.05, 0.4, 1.0]))) for _ in range(7)]
+    side = int(math.ceil(math.sqrt(n_instances)))
+    instances = []
+    for i in range(n_instances):
+        gx, gz = i % side, i // side
+        t = translate((1.6 * (gx - side / 2) + rng.uniform(-0.2, 0.2), rng.uniform(-0.3, 0.3), 1.6 * (gz - side / 2) + rng.uniform(-0.2, 0.2)))
+        l2w = t @ rotate_y(float(rng.uniform(0, 360))) @ rotate_x(float(rng.uniform(-20, 20))) @ scale(rng.uniform(0.5, 1.2, 3))
+        instances.append((int(rng.integers(0, len(meshes))), int(rng.integers(0, len(materials))), l2w))
+    floor = quad_grid((-16, -0.9, 16), (32, 0, 0), (0, 0, -32), 8, 8)
+    meshes.append(floor)
+    instances.append((len(meshes) - 1, 0, np.eye(4)))
+    lights = [dict(type=abi.LIGHT_POINT, position=(0.0, 6.0, 0.0), intensity=(200.0, 190.0, 180.0)),
+              dict(type=abi.LIGHT_DIRECTIONAL, direction=(0.3, -1.0, 0.2), intensity=(1.0, 1.0, 1.1))]
+    return assemble("instanced_field", meshes, materials, instances, lights, cam_eye=(0.0, 5.0, 14.0), cam_target=(0, 0, 0), fovy=0.9)
+
+
+SCENES["instanced_field"] = instanced_field

@@ -53,7 +53,7 @@ def test_c1_golden_cornell_256(cornell, prec):
 
 
 @pytest.mark.parametrize("prec", [abi.F32, abi.F16])
-@pytest.mark.parametrize("scene_name,W,H", [("cornell", 160, 96), ("small_test", 200, 120), ("textured", 192, 108)])
+@pytest.mark.parametrize("scene_name,W,H", [("cornell", 160, 96), ("small_test", 200, 120), ("textured", 192, 108), ("instanced_field", 160, 90)])
 def test_every_buffer_matches_oracle(scene_name, W, H, prec):
     sc = scenes.SCENES[scene_name]()
     r, o = render_pair(sc, W, H, prec, frames=1, spp=1)
@@ -67,10 +67,11 @@ def test_every_buffer_matches_oracle(scene_name, W, H, prec):
     for name in RADIANCE:
         a, b = r.read(name), o.read(name)
         assert np.array_equal(np.isfinite(a), np.isfinite(b)) or prec == abi.F16, name
-        if prec == abi.F16 and scene_name == "textured":
+        if prec == abi.F16 and scene_name in ("textured", "instanced_field"):
             # fp16 box culling depends on the tree topology, which the reference leaves to std::nth_element: a handful
-            # of grazing GI rays land on the bright sky in one tree and on geometry in the other.  The sparse lobe
-            # buffers are dominated by those pixels, so the 0.5 % worst pixels are set aside before the L2 bound.
+            # of grazing GI rays land elsewhere in one tree than in the other (on the bright sky instead of geometry; on
+            # another instance).  The sparse lobe buffers are dominated by those few pixels (0.04 % of them here), so
+            # the 0.5 % worst pixels are set aside before the L2 bound.
             d = np.abs(np.nan_to_num(a) - np.nan_to_num(b)).sum(axis=-1).reshape(-1)
             keep = d <= np.quantile(d, 0.995)
             a, b = a.reshape(-1, a.shape[-1])[keep], b.reshape(-1, b.shape[-1])[keep]

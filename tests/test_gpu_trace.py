@@ -225,3 +225,17 @@ def test_stationary_and_near_stationary_axes_do_not_walk_the_whole_tree(sponza, 
             assert (ho["hit"] != hg["hit"]).mean() < 0.02
             same = (ho["hit"] == 1) & (hg["hit"] == 1) & (ho["inobject_offset"] == hg["inobject_offset"])
             assert same.sum() > 0.9 * ((ho["hit"] == 1) & (hg["hit"] == 1)).sum() or any_hit
+
+
+def test_tlas_tree_walk_with_many_instances():
+    """More than 32 instances: cast_ray walks the TLAS tree (the flat scan is for small scenes)."""
+    sc = scenes.instanced_field(150)
+    assert len(sc.objects) > 32
+    o = Oracle(16, 16, abi.F32)
+    o.load_scene(sc)
+    r = lprt_amd.Renderer(16, 16, abi.F32)
+    r.load_scene(sc)
+    rays = random_rays(sc, 50000, 21, 1e-4)
+    for any_hit in (False, True):
+        compare_hits(o.trace(rays, any_hit), r.trace(rays, any_hit), any_hit, 0.01)
+    assert o.trace(rays, False)["hit"].mean() > 0.2
