@@ -1,0 +1,76 @@
+"""The N > 1 path end to end on one GPU: two ranks (gloo transport, both rendering on cuda:0) run the code bench.py runs
+per frame — render the strip + halo, exchange the halo rows' temporal history point-to-point, all-gather the image — and
+every gathered frame must equal the single-context frame bit for bit."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rank(rank, world, port, W, H, frames, q):
+    import torch
+    import torch.distributed as tdist
+    import lprt_amd
+    from lprt_amd import abi, scenes, dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    sc = scenes.cornell_box()
+    wb, we = dist.window_rows(H, world, rank)
+    r = lprt_amd.Renderer(W, H, abi.F32, device=0, row_begin=wb, row_end=we)
+    r.set_stream(torch.cuda.current_stream().cuda_stream)
+    frame = dist.ShardedFrame(W, H, rank, world, torch.device("cuda", 0), backend="gloo")
+    r.set_output_target(*frame.target())
+    r.load_scene(sc)
+    out = []
+    for _ in range(frames):
+        r.set_scene(sc)
+        r.render(abi.default_settings(spp=1))
+        moved = frame.exchange_history(r)
+        img = frame.all_gather()
+        torch.cuda.synchronize()
+        out.append(img.cpu().numpy().copy())
+    q.put((rank, out, moved))
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+def test_two_ranks_render_exchange_gather_equal_one_context():
+    import torch.multiprocessing as mp
+    import lprt_amd
+    from lprt_amd import abi, scenes
+    W, H, frames, world = 128, 288, 3, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank, args=(r, world, port, W, H, frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    sc = scenes.cornell_box()
+    full = lprt_amd.Renderer(W, H, abi.F32)
+    full.load_scene(sc)
+    want = []
+    for _ in range(frames):
+        full.set_scene(sc)
+        full.render(abi.default_settings(spp=1))
+        want.append(full.read("OUTPUT"))
+    for rank, out, moved in got:
+        assert moved > 0
+        for k in range(frames):
+            assert np.array_equal(out[k], want[k], equal_nan=True), f"rank {rank} frame {k}"
