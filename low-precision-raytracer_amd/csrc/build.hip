@@ -304,6 +304,116 @@ __host__ __device__ inline void segment_at(uint32_t q, uint32_t d, uint32_t n, u
             l = mid;
     }
 }
+// ---- the lower levels of the median-split ordering, one workgroup per subtree -----------------------------------------
+// Once every node of a level holds at most LOCAL_MAX triangles, the rest of that subtree's ordering needs only the
+// subtree's own elements: one workgroup keeps them in LDS and runs the remaining levels there — per level the bounds of
+// every sub-node (LDS atomics in order-preserving int space), the same 16-bit key along the sub-node's longest axis as
+// k_seg_keys, and a bitonic sort of the composite key (sub-node | key | current position).  The position in the low bits
+// makes the order total, so the result is exactly the stable sort the global radix passes produce: the permutation is
+// bit-identical to the all-global build (LPRT_BLAS_LOCAL=0), at one launch instead of 18 per level.
+constexpr uint32_t LOCAL_MAX = 1024;
+struct LocalJob {
+    uint32_t prim, first, count, depth0; // triangles [first, first + count) of the primitive's sorted range; node depth
+};
+__global__ void __launch_bounds__(256) k_local_levels(uint32_t *perm, const float *tri_bounds, const BlasInfo *blas, const LocalJob *jobs) {
+    __shared__ unsigned long long key[LOCAL_MAX];
+    __shared__ uint32_t val[LOCAL_MAX];
+    __shared__ int bnd[LOCAL_MAX][6];
+    const LocalJob job = jobs[blockIdx.x];
+    const BlasInfo bi = blas[job.prim];
+    const uint32_t n = job.count, tid = threadIdx.x;
+    uint32_t *gperm = perm + bi.tri_base + job.first;
+    for (uint32_t e = tid; e < LOCAL_MAX; e += 256)
+        val[e] = e < n ? gperm[e] : 0xffffffffu;
+    __syncthreads();
+    for (uint32_t d = job.depth0; d < bi.depth; d++) {
+        const uint32_t n_sub = 1u << (d - job.depth0);
+        for (uint32_t i = tid; i < n_sub * 6; i += 256)
+            bnd[i / 6][i % 6] = (i % 6) < 3 ? 0x7fffffff : (int)0x80000000;
+        __syncthreads();
+        // 1. bounds of every sub-node: union of its triangles' boxes
+        for (uint32_t e = tid; e < n; e += 256) {
+            uint32_t l = 0, r = bi.n_tris, j = 0;
+            const uint32_t q = job.first + e;
+            for (uint32_t b = 0; b < d; b++) {
+                const uint32_t mid = l + (r - l) / 2;
+                j <<= 1;
+                if (q < mid) {
+                    r = mid;
+                } else {
+                    l = mid;
+                    j |= 1u;
+                }
+            }
+            const uint32_t js = j & (n_sub - 1u);
+            const float *b = tri_bounds + 6 * (size_t)val[e];
+            for (int k = 0; k < 3; k++) {
+                atomicMin(&bnd[js][k], f32_ordered(b[k]));
+                atomicMax(&bnd[js][3 + k], f32_ordered(b[3 + k]));
+            }
+        }
+        __syncthreads();
+        // 2. composite keys
+        for (uint32_t e = tid; e < LOCAL_MAX; e += 256) {
+            unsigned long long kk = ~0ull; // padding sorts to the end
+            if (e < n) {
+                uint32_t l = 0, r = bi.n_tris, j = 0;
+                const uint32_t q = job.first + e;
+                for (uint32_t b = 0; b < d; b++) {
+                    const uint32_t mid = l + (r - l) / 2;
+                    j <<= 1;
+                    if (q < mid) {
+                        r = mid;
+                    } else {
+                        l = mid;
+                        j |= 1u;
+                    }
+                }
+                const uint32_t js = j & (n_sub - 1u);
+                float lo[3], hi[3];
+                for (int k = 0; k < 3; k++) {
+                    lo[k] = f32_unordered(bnd[js][k]);
+                    hi[k] = f32_unordered(bnd[js][3 + k]);
+                }
+                const float w0 = hi[0] - lo[0], w1 = hi[1] - lo[1], w2 = hi[2] - lo[2];
+                int axis = 0; // strictly longest axis, x on ties (object_bvh.hpp:111-119)
+                if (w1 > w0 && w1 > w2)
+                    axis = 1;
+                else if (w2 > w0 && w2 > w1)
+                    axis = 2;
+                const float *b = tri_bounds + 6 * (size_t)val[e];
+                const float c = 0.5f * (b[axis] + b[3 + axis]);
+                const float ext = hi[axis] - lo[axis];
+                const float qq = ext > 0.0f ? (c - lo[axis]) / ext : 0.0f;
+                const uint32_t q16 = (uint32_t)fminf(fmaxf(qq * 65535.0f, 0.0f), 65535.0f);
+                kk = ((unsigned long long)js << 26) | ((unsigned long long)q16 << 10) | e;
+            }
+            key[e] = kk;
+        }
+        __syncthreads();
+        // 3. bitonic sort of (key, val) over LOCAL_MAX slots
+        for (uint32_t k2 = 2; k2 <= LOCAL_MAX; k2 <<= 1)
+            for (uint32_t j2 = k2 >> 1; j2 > 0; j2 >>= 1) {
+                for (uint32_t i = tid; i < LOCAL_MAX; i += 256) {
+                    const uint32_t x = i ^ j2;
+                    if (x > i) {
+                        const unsigned long long a = key[i], b = key[x];
+                        const bool up = (i & k2) == 0;
+                        if ((a > b) == up) {
+                            key[i] = b;
+                            key[x] = a;
+                            const uint32_t t = val[i];
+                            val[i] = val[x];
+                            val[x] = t;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+    }
+    for (uint32_t e = tid; e < n; e += 256)
+        gperm[e] = val[e];
+}
 __global__ void k_iota(uint32_t *p, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n)
@@ -748,7 +858,40 @@ template <typename T> void GeometryStore<T>::build_blas(hipStream_t st) {
             shifts.push_back(16 + (int)b);
         d_seg_bounds.reserve(sizeof(int) * 6 * (size_t)n_tris);
         hipLaunchKernelGGL(k_iota, dim3(tb), dim3(256), 0, st, d_vals[cur].as<uint32_t>(), n_tris);
-        for (uint32_t d = 0; d < max_depth; d++) {
+        // levels walked by the global sort: until every node of every primitive holds <= LOCAL_MAX triangles
+        uint32_t global_levels = max_depth;
+        const char *lsel = std::getenv("LPRT_BLAS_LOCAL");
+        const bool use_local = !(lsel && std::string(lsel) == "0");
+        std::vector<LocalJob> jobs;
+        if (use_local) {
+            global_levels = 0;
+            for (const BlasInfo &bi : host_blas) {
+                uint32_t d = 0;
+                while (d < bi.depth && ((bi.n_tris + (1u << d) - 1) >> d) > LOCAL_MAX)
+                    d++;
+                global_levels = std::max(global_levels, d);
+            }
+            for (uint32_t p = 0; p < n_vaos; p++) {
+                const BlasInfo &bi = host_blas[p];
+                if (bi.depth <= global_levels)
+                    continue; // this primitive's ordering is complete after the global levels
+                for (uint32_t j = 0; j < (1u << global_levels); j++) {
+                    uint32_t l = 0, r = bi.n_tris;
+                    for (uint32_t b = 0; b < global_levels; b++) {
+                        const uint32_t mid = l + (r - l) / 2;
+                        if ((j >> (global_levels - 1 - b)) & 1u)
+                            l = mid;
+                        else
+                            r = mid;
+                    }
+                    if (r - l > LOCAL_MAX)
+                        throw std::string("internal: local BLAS segment larger than LOCAL_MAX");
+                    if (r > l)
+                        jobs.push_back(LocalJob{p, l, r - l, global_levels});
+                }
+            }
+        }
+        for (uint32_t d = 0; d < global_levels; d++) {
             hipLaunchKernelGGL(k_init_bounds, dim3((6 * n_tris + 255) / 256), dim3(256), 0, st, d_seg_bounds.as<int>(), n_tris);
             hipLaunchKernelGGL(k_seg_bounds, dim3(tb), dim3(256), 0, st, d_vals[cur].as<uint32_t>(), d_tri_bounds.as<float>(),
                                d_tri_prim.as<uint32_t>(), d_blas.as<BlasInfo>(), n_tris, d, d_seg_bounds.as<int>());
@@ -756,6 +899,13 @@ template <typename T> void GeometryStore<T>::build_blas(hipStream_t st) {
                                d_tri_prim.as<uint32_t>(), d_blas.as<BlasInfo>(), n_tris, d, d_seg_bounds.as<int>(),
                                d_keys[cur].as<unsigned long long>());
             radix_sort(st, shifts, cur);
+        }
+        if (!jobs.empty()) {
+            d_local_jobs.reserve(sizeof(LocalJob) * jobs.size());
+            LPRT_HIP(hipMemcpyAsync(d_local_jobs.ptr, jobs.data(), sizeof(LocalJob) * jobs.size(), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_local_levels, dim3((uint32_t)jobs.size()), dim3(256), 0, st, d_vals[cur].as<uint32_t>(), d_tri_bounds.as<float>(),
+                               d_blas.as<BlasInfo>(), d_local_jobs.as<LocalJob>());
+            LPRT_HIP(hipStreamSynchronize(st)); // `jobs` is host memory that goes away
         }
     }
     sorted_buf = cur;

@@ -239,3 +239,19 @@ def test_tlas_tree_walk_with_many_instances():
     for any_hit in (False, True):
         compare_hits(o.trace(rays, any_hit), r.trace(rays, any_hit), any_hit, 0.01)
     assert o.trace(rays, False)["hit"].mean() > 0.2
+
+
+def test_local_subtree_ordering_equals_the_all_global_build(sponza, small_scene, monkeypatch):
+    """build.hip: below 1024 triangles per node one workgroup finishes the subtree's median ordering in LDS (bitonic sort
+    of sub-node | key | position); the permutation must be the one the level-by-level global radix sorts produce."""
+    for sc in (small_scene, sponza):
+        orders = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("LPRT_BLAS_LOCAL", mode)
+            r = lprt_amd.Renderer(16, 16, abi.F32)
+            r.set_rdresource(sc)
+            orders[mode] = [r.blas_order(v) for v in range(len(sc.vaos))]
+            r.close()
+        for a, b in zip(orders["0"], orders["1"]):
+            assert np.array_equal(a, b)
+            assert np.array_equal(np.sort(a), np.arange(len(a)))
