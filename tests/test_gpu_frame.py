@@ -387,3 +387,44 @@ def test_odd_frame_sizes_hit_every_tile_edge(cornell, W, H, prec):
     r, o = render_pair(cornell, W, H, prec, frames=2, spp=2)
     for name in ("COLOR_INPROGRESS", "MUL_GI_COLORED", "MUL_GI_WHITE", "OUTPUT"):
         assert rel_l2(r.read(name), o.read(name)) < TOL[prec], name
+
+
+def test_degenerate_scenes_render_without_faults(cornell):
+    """No instances at all, no lights, an instance of an empty primitive: frames complete and stay finite/black where
+    nothing is visible (empty inputs)."""
+    import copy
+    W, H = 64, 40
+    # 1. geometry uploaded, but the scene holds no instance and no light
+    empty = copy.copy(cornell)
+    empty.objects, empty.aabbs, empty.lights = [], cornell.aabbs[:0], []
+    r = lprt_amd.Renderer(W, H, abi.F32)
+    r.set_rdresource(cornell)
+    r.set_scene(empty)
+    for _ in range(2):
+        r.render(abi.default_settings(spp=2))
+    out = r.read("OUTPUT")
+    assert (r.read("G_COLOR")[..., 3] == 0).all() and np.isfinite(out).all() and (out[..., :3] == 0).all()
+    assert len(r.trace(np.zeros(4, dtype=abi.RAY_DTYPE))) == 4
+    # 2. Cornell without lights: only the emitter and GI light the frame
+    dark = copy.copy(cornell)
+    dark.lights = []
+    o = Oracle(W, H, abi.F32)
+    o.load_scene(dark)
+    r2 = lprt_amd.Renderer(W, H, abi.F32)
+    r2.load_scene(dark)
+    o.render_frame(abi.default_settings(spp=1))
+    r2.render(abi.default_settings(spp=1))
+    assert rel_l2(r2.read("OUTPUT"), o.read("OUTPUT")) < 1e-3
+    # 3. a primitive with no triangles next to ordinary ones
+    sc = scenes.small_test_scene()
+    sc.vaos = np.concatenate([sc.vaos, np.array([[0, 0, len(sc.indices), 0]], dtype=np.uint32)])
+    sc.local_aabbs = np.concatenate([sc.local_aabbs, np.zeros((1, 6), dtype=np.float32)])
+    sc.objects = sc.objects + [dict(L2W=np.eye(4, dtype=np.float32), W2L=np.eye(4, dtype=np.float32), materialid=0, objectid=len(sc.vaos) - 1)]
+    sc.aabbs = np.concatenate([sc.aabbs, np.array([[-1, -1, -1, 1, 1, 1]], dtype=np.float32)])
+    r3 = lprt_amd.Renderer(W, H, abi.F32)
+    r3.load_scene(sc)
+    r3.render(abi.default_settings(spp=1))
+    ref = lprt_amd.Renderer(W, H, abi.F32)
+    ref.load_scene(scenes.small_test_scene())
+    ref.render(abi.default_settings(spp=1))
+    assert np.array_equal(r3.read("OUTPUT"), ref.read("OUTPUT"), equal_nan=True)
