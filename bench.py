@@ -78,6 +78,14 @@ def measure(prec, sc, W, H, spp, steps, warmup, rank, world, device, stage_timin
     ptr, first_row, n_rows = frame.target()
     r.set_output_target(ptr, first_row, n_rows)
     r.load_scene(sc)
+    # BVH build rate, reported apart: BLAS of every primitive, three timed rebuilds after the first
+    r.enable_stage_timing(True)
+    r.reset_stage_times()
+    for _ in range(3):
+        r.build_blas()
+    r.synchronize()
+    build_ms = r.stage_times()["build_blas"][0] / 3
+    r.enable_stage_timing(False)
     fs = abi.default_settings(spp=spp, gi_on=True, svgf=True)
 
     last = {}
@@ -152,7 +160,7 @@ def measure(prec, sc, W, H, spp, steps, warmup, rank, world, device, stage_timin
     out_ok = bool(torch.isfinite(last["image"]).all().item()) and bool((last["image"][..., 3] == 1).all().item())
     res = dict(dt=dt, ms_per_step=1e3 * dt / steps, frames_per_s=steps / dt, frame_rays=frame_rays,
                mrays_per_s=frame_rays * steps / dt / 1e6, stage=stage, calib=calib, stage_counters=stage_counters,
-               finite=out_ok, window_rows=[win_b, win_e])
+               finite=out_ok, window_rows=[win_b, win_e], build_blas_ms=build_ms)
     r.close()
     return res
 
@@ -280,6 +288,9 @@ def main():
                        "triangles": sc.n_tris, "objects": len(sc.objects), "rays_per_frame": res32["frame_rays"],
                        "parallelism": f"row-strips x{world} + halo {lp_dist.HALO_ROWS} + all-gather" if world > 1 else "single GPU"},
             "frames_per_s": res32["frames_per_s"],
+            "mrays_per_s_trace_kernels_only": (res32["frame_rays"] / 1e3 / sum(res32["calib"][k][0] for k in ("primary", "trace_di1", "trace_gi", "trace_di2")
+                                                                                  if k in res32["calib"])) if res32["calib"] else None,
+            "build_blas_ms": res32["build_blas_ms"], "build_mtris_per_s": sc.n_tris / 1e3 / res32["build_blas_ms"],
             "output_finite": res32["finite"],
             "stage_ms_per_frame": {k: v[0] for k, v in res32["calib"].items()},
             "stage_ms_note": "3 untimed calibration frames with every stage bracketed by HIP events; the timed region "
