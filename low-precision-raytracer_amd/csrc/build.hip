@@ -464,18 +464,34 @@ __global__ void k_seg_bounds(const uint32_t *perm, const float *tri_bounds, cons
         }
     }
 }
+// rank_base (optional): per primitive, the number of level-d nodes of the primitives before it.  The high part of the key is
+// then the dense node rank instead of the node's start position — the same order with far fewer bits to sort (the few
+// thousand nodes of the upper levels need 12 bits, a position needs 18).
 __global__ void k_seg_keys(const uint32_t *perm, const float *tri_bounds, const uint32_t *tri_prim, const BlasInfo *blas, uint32_t n_tris, uint32_t d,
-                           const int *seg_bounds, unsigned long long *keys) {
+                           const int *seg_bounds, unsigned long long *keys, const uint32_t *rank_base) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_tris)
         return;
-    const BlasInfo bi = blas[tri_prim[s]];
+    const uint32_t prim = tri_prim[s];
+    const BlasInfo bi = blas[prim];
     if (d >= bi.depth) { // this primitive's tree is complete: keep the element where it is
-        keys[s] = (unsigned long long)s << 16;
+        keys[s] = rank_base ? (((unsigned long long)rank_base[prim] << 16) | (s - bi.tri_base)) : ((unsigned long long)s << 16);
         return;
     }
-    uint32_t l, r;
-    segment_at(s - bi.tri_base, d, bi.n_tris, l, r);
+    uint32_t l = 0, r = bi.n_tris, j = 0;
+    {
+        const uint32_t q = s - bi.tri_base;
+        for (uint32_t b = 0; b < d; b++) {
+            const uint32_t mid = l + (r - l) / 2;
+            j <<= 1;
+            if (q < mid) {
+                r = mid;
+            } else {
+                l = mid;
+                j |= 1u;
+            }
+        }
+    }
     const uint32_t seg = bi.tri_base + l;
     float lo[3], hi[3];
     for (int k = 0; k < 3; k++) {
@@ -493,7 +509,7 @@ __global__ void k_seg_keys(const uint32_t *perm, const float *tri_bounds, const 
     const float ext = hi[axis] - lo[axis];
     const float q = ext > 0.0f ? (c - lo[axis]) / ext : 0.0f;
     const uint32_t q16 = (uint32_t)fminf(fmaxf(q * 65535.0f, 0.0f), 65535.0f);
-    keys[s] = ((unsigned long long)seg << 16) | q16;
+    keys[s] = ((unsigned long long)(rank_base ? rank_base[prim] + j : seg) << 16) | q16;
 }
 
 // ---- tree emission ---------------------------------------------------------------------------------
@@ -891,13 +907,41 @@ template <typename T> void GeometryStore<T>::build_blas(hipStream_t st) {
                 }
             }
         }
+        // dense node ranks for the key's high part (see k_seg_keys); positions when a finished primitive is too large for 16 bits
+        std::vector<uint32_t> rank_bases((size_t)global_levels * n_vaos, 0u);
+        std::vector<uint32_t> level_nodes(global_levels, 0u);
+        bool dense = global_levels > 0;
         for (uint32_t d = 0; d < global_levels; d++) {
+            uint32_t acc = 0;
+            for (uint32_t p = 0; p < n_vaos; p++) {
+                rank_bases[(size_t)d * n_vaos + p] = acc;
+                const BlasInfo &bi = host_blas[p];
+                acc += d < bi.depth ? (1u << d) : 1u;
+                if (d >= bi.depth && bi.n_tris > 65536u)
+                    dense = false;
+            }
+            level_nodes[d] = acc;
+        }
+        if (dense) {
+            d_rank_bases.reserve(sizeof(uint32_t) * rank_bases.size());
+            LPRT_HIP(hipMemcpyAsync(d_rank_bases.ptr, rank_bases.data(), sizeof(uint32_t) * rank_bases.size(), hipMemcpyHostToDevice, st));
+            LPRT_HIP(hipStreamSynchronize(st));
+        }
+        for (uint32_t d = 0; d < global_levels; d++) {
+            if (dense) {
+                uint32_t bits = 1;
+                while ((1u << bits) < level_nodes[d])
+                    bits++;
+                shifts = {0, 8};
+                for (uint32_t b = 0; b < bits; b += 8)
+                    shifts.push_back(16 + (int)b);
+            }
             hipLaunchKernelGGL(k_init_bounds, dim3((6 * n_tris + 255) / 256), dim3(256), 0, st, d_seg_bounds.as<int>(), n_tris);
             hipLaunchKernelGGL(k_seg_bounds, dim3(tb), dim3(256), 0, st, d_vals[cur].as<uint32_t>(), d_tri_bounds.as<float>(),
                                d_tri_prim.as<uint32_t>(), d_blas.as<BlasInfo>(), n_tris, d, d_seg_bounds.as<int>());
             hipLaunchKernelGGL(k_seg_keys, dim3(tb), dim3(256), 0, st, d_vals[cur].as<uint32_t>(), d_tri_bounds.as<float>(),
                                d_tri_prim.as<uint32_t>(), d_blas.as<BlasInfo>(), n_tris, d, d_seg_bounds.as<int>(),
-                               d_keys[cur].as<unsigned long long>());
+                               d_keys[cur].as<unsigned long long>(), dense ? d_rank_bases.as<uint32_t>() + (size_t)d * n_vaos : nullptr);
             radix_sort(st, shifts, cur);
         }
         if (!jobs.empty()) {

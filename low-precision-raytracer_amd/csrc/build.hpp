@@ -13,7 +13,7 @@ template <typename T> struct GeometryStore {
     std::vector<BlasInfo> host_blas;
     DevBuf d_vbo32, d_vbo, d_ebo, d_vaos, d_tri_prim, d_blas;
     DevBuf d_mf32, d_tri_bounds, d_sorted_bounds, d_prim_cbounds, d_keys[2], d_vals[2], d_hist;
-    DevBuf d_tris, d_tris_f32, d_inner, d_leaf, d_roots, d_seg_bounds, d_local_jobs;
+    DevBuf d_tris, d_tris_f32, d_inner, d_leaf, d_roots, d_seg_bounds, d_local_jobs, d_rank_bases;
 
     // RDResource::{objects_vbo, objects_ebo, objects_vao} + vertex conversion (memory.hpp:568-619)
     void upload(hipStream_t st, const lprt_vertex *vbo, uint32_t nv, const uint32_t *ebo, uint32_t ni, const lprt_mesh_vao *vaos,
