@@ -94,7 +94,7 @@ def measure(prec, sc, W, H, spp, steps, warmup, rank, world, device, stage_timin
         r.set_scene(sc)   # per-frame RDScene hand-over + TLAS rebuild (rt/rtrt/cuda.hpp:662-710)
         r.render(fs)
         if world > 1:     # temporal history of the halo rows comes from the ranks that own them (dist.py)
-            last["hist_bytes"] = frame.exchange_history(r)
+            last["hist_bytes"] = frame.exchange_history(r, stream_ordered=True)  # r enqueues on torch's current stream
         last["image"] = frame.all_gather()
 
     # rays of one whole frame (full image, rank 0) and per-kernel work counters of THIS rank's launches: one

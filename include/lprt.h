@@ -295,10 +295,13 @@ int lprt_set_output_target(lprt_ctx *ctx, void *dst_device, uint32_t first_row, 
  * of both lobes, TAA history, frame counters) is only right on the rows a context OWNS; its halo rows lack part of
  * their filter support.  After each frame a rank exports the owned rows its neighbours hold as halo and imports its
  * own halo rows from their owners.  Rows are image rows inside the context's window; the packed buffer is device
- * memory of n_rows * lprt_history_row_bytes() bytes (plane after plane), enqueued on the context's stream. */
-int lprt_history_row_bytes(lprt_ctx *ctx, size_t *bytes);
-int lprt_export_history_rows(lprt_ctx *ctx, uint32_t first_row, uint32_t n_rows, void *dst_device);
-int lprt_import_history_rows(lprt_ctx *ctx, uint32_t first_row, uint32_t n_rows, const void *src_device);
+ * memory of n_rows * lprt_history_row_bytes(groups) bytes (plane after plane of the chosen groups), one kernel on the
+ * context's stream. */
+#define LPRT_HIST_FILTER 1u /* SVGF colour + moment history of both lobes, frame counters: needed on the whole halo */
+#define LPRT_HIST_TAA 2u    /* TAA history: read only within +-1 row (+ motion) of the rows a context owns */
+int lprt_history_row_bytes(lprt_ctx *ctx, uint32_t groups, size_t *bytes);
+int lprt_export_history_rows(lprt_ctx *ctx, uint32_t groups, uint32_t first_row, uint32_t n_rows, void *dst_device);
+int lprt_import_history_rows(lprt_ctx *ctx, uint32_t groups, uint32_t first_row, uint32_t n_rows, const void *src_device);
 
 /* cast_ray<find_any,false> over a host ray batch (rt/rtrt/cuda.hpp:622-631), for hit-record parity
  * and ray-rate measurement; rays are rounded to DataT on the device like a TraceGICommand. */

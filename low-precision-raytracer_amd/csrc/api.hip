@@ -74,27 +74,40 @@ struct CtxBase {
     struct HistPlane {
         void *ptr;
         size_t bytes_per_pixel;
+        uint32_t group; // LPRT_HIST_FILTER | LPRT_HIST_TAA
     };
     virtual std::vector<HistPlane> history_planes() = 0;
-    size_t history_row_bytes() {
+    size_t history_row_bytes(uint32_t groups) {
         size_t b = 0;
         for (auto &pl : history_planes())
-            b += pl.bytes_per_pixel;
+            if (groups & pl.group)
+                b += pl.bytes_per_pixel;
         return b * win.W;
     }
-    // rows [first_row, first_row + n_rows) of every history plane <-> one packed device buffer, plane after plane
-    void copy_history_rows(uint32_t first_row, uint32_t n_rows, void *packed, bool to_packed) {
+    // rows [first_row, first_row + n_rows) of the history planes of the given groups <-> one packed device buffer, plane
+    // after plane: ONE kernel launch (a plane's rows are contiguous, so each plane is a flat byte range)
+    void copy_history_rows(uint32_t groups, uint32_t first_row, uint32_t n_rows, void *packed, bool to_packed) {
         if (first_row < win.row_begin || first_row + n_rows > win.row_end)
             throw std::string("history rows must lie inside this context's row window");
-        size_t off = 0;
+        CopyJobs jobs{};
+        size_t off = 0, longest = 0;
         for (auto &pl : history_planes()) {
+            if (!(groups & pl.group))
+                continue;
             const size_t row = pl.bytes_per_pixel * win.W, bytes = row * n_rows;
             char *plane = static_cast<char *>(pl.ptr) + row * (first_row - win.row_begin);
             char *pk = static_cast<char *>(packed) + off;
-            if (bytes)
-                LPRT_HIP(hipMemcpyAsync(to_packed ? (void *)pk : (void *)plane, to_packed ? (void *)plane : (void *)pk, bytes, hipMemcpyDeviceToDevice, stream));
+            if (jobs.n >= LPRT_MAX_COPY_JOBS)
+                throw std::string("internal: too many history planes");
+            jobs.src[jobs.n] = to_packed ? plane : pk;
+            jobs.dst[jobs.n] = to_packed ? pk : plane;
+            jobs.bytes[jobs.n] = bytes;
+            jobs.n++;
+            longest = std::max(longest, bytes);
             off += bytes;
         }
+        if (jobs.n && longest)
+            launch_copy_jobs(stream, jobs, longest);
     }
     bool counters_enabled = false;
     StageTimer timer;
@@ -409,13 +422,13 @@ template <typename T> struct Impl : CtxBase {
         ensure_frame_buffers();
         std::vector<HistPlane> v;
         for (int l = 0; l < 2; l++)
-            v.push_back({fb.lobe[l].cv_b, sizeof(V4<T>)});
+            v.push_back({fb.lobe[l].cv_b, sizeof(V4<T>), LPRT_HIST_FILTER});
         for (int l = 0; l < 2; l++) {
-            v.push_back({fb.lobe[l].miu1_hist, sizeof(T)});
-            v.push_back({fb.lobe[l].miu2_hist, sizeof(T)});
+            v.push_back({fb.lobe[l].miu1_hist, sizeof(T), LPRT_HIST_FILTER});
+            v.push_back({fb.lobe[l].miu2_hist, sizeof(T), LPRT_HIST_FILTER});
         }
-        v.push_back({fb.taa_history, sizeof(V4<T>)});
-        v.push_back({fb.prev_frame_count, 1});
+        v.push_back({fb.prev_frame_count, 1, LPRT_HIST_FILTER});
+        v.push_back({fb.taa_history, sizeof(V4<T>), LPRT_HIST_TAA});
         return v;
     }
     void output_ptr(void **ptr, size_t *bytes) override {
@@ -865,25 +878,25 @@ int lprt_set_output_target(lprt_ctx *ctx, void *dst, uint32_t first_row, uint32_
         c.ext_rows = dst ? n_rows : 0;
     });
 }
-int lprt_history_row_bytes(lprt_ctx *ctx, size_t *bytes) {
+int lprt_history_row_bytes(lprt_ctx *ctx, uint32_t groups, size_t *bytes) {
     return guarded(ctx, [&](CtxBase &c) {
         if (!bytes)
             throw std::string("null out pointer");
-        *bytes = c.history_row_bytes();
+        *bytes = c.history_row_bytes(groups);
     });
 }
-int lprt_export_history_rows(lprt_ctx *ctx, uint32_t first_row, uint32_t n_rows, void *dst_device) {
+int lprt_export_history_rows(lprt_ctx *ctx, uint32_t groups, uint32_t first_row, uint32_t n_rows, void *dst_device) {
     return guarded(ctx, [&](CtxBase &c) {
         if (n_rows && !dst_device)
             throw std::string("null history buffer");
-        c.copy_history_rows(first_row, n_rows, dst_device, true);
+        c.copy_history_rows(groups, first_row, n_rows, dst_device, true);
     });
 }
-int lprt_import_history_rows(lprt_ctx *ctx, uint32_t first_row, uint32_t n_rows, const void *src_device) {
+int lprt_import_history_rows(lprt_ctx *ctx, uint32_t groups, uint32_t first_row, uint32_t n_rows, const void *src_device) {
     return guarded(ctx, [&](CtxBase &c) {
         if (n_rows && !src_device)
             throw std::string("null history buffer");
-        c.copy_history_rows(first_row, n_rows, const_cast<void *>(src_device), false);
+        c.copy_history_rows(groups, first_row, n_rows, const_cast<void *>(src_device), false);
     });
 }
 int lprt_debug_rng_states(lprt_ctx *ctx, uint64_t seed, uint32_t first, uint32_t count, uint32_t *out) {

@@ -14,6 +14,15 @@ template <typename T> void launch_convert_objects(hipStream_t st, const lprt_obj
 template <typename T> void launch_convert_materials(hipStream_t st, const lprt_material *in, MaterialT<T> *out, uint32_t n);
 template <typename T> void launch_convert_lights(hipStream_t st, const lprt_light *in, LightT<T> *out, uint32_t n);
 template <typename T> void launch_convert_mat4(hipStream_t st, const float *in, M4<T> *out, uint32_t n);
+// up to LPRT_MAX_COPY_JOBS flat device-to-device byte copies in one launch (history-plane pack / unpack)
+#define LPRT_MAX_COPY_JOBS 12
+struct CopyJobs {
+    const void *src[LPRT_MAX_COPY_JOBS];
+    void *dst[LPRT_MAX_COPY_JOBS];
+    size_t bytes[LPRT_MAX_COPY_JOBS];
+    uint32_t n;
+};
+void launch_copy_jobs(hipStream_t st, const CopyJobs &jobs, size_t longest);
 void launch_sample_texture(hipStream_t st, const Texture *textures, const float *lut, uint32_t handle, const float *uv, uint32_t n, float *rgba);
 
 

@@ -1,6 +1,7 @@
 // Ray-casting kernels: host ray batches (lprt_trace_rays), primary rays -> G-buffer (G1, G2),
 // GI rays (TG) and shadow rays (TD).
 #include "kernels.hpp"
+#include <algorithm>
 #include "shade.hpp"
 #include "trace.hpp"
 
@@ -161,6 +162,29 @@ template <typename T> void launch_convert_mat4(hipStream_t st, const float *in, 
     if (n)
         hipLaunchKernelGGL(k_convert_mat4<T>, dim3((n * 16 + 63) / 64), dim3(64), 0, st, in, out, n);
 }
+// blockIdx.y = job; 16-byte words when both ends and the length allow it, bytes otherwise (uint8 planes, odd widths)
+__global__ void k_copy_jobs(CopyJobs jobs) {
+    const uint32_t j = blockIdx.y;
+    const char *src = static_cast<const char *>(jobs.src[j]);
+    char *dst = static_cast<char *>(jobs.dst[j]);
+    const size_t n = jobs.bytes[j];
+    const bool wide = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst) | n) & 15u) == 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x, i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wide) {
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+        uint4 *d4 = reinterpret_cast<uint4 *>(dst);
+        for (size_t i = i0; i < n / 16; i += stride)
+            d4[i] = s4[i];
+    } else {
+        for (size_t i = i0; i < n; i += stride)
+            dst[i] = src[i];
+    }
+}
+void launch_copy_jobs(hipStream_t st, const CopyJobs &jobs, size_t longest) {
+    const uint32_t bx = (uint32_t)std::min<size_t>((longest / 16 + 255) / 256 + 1, 2048);
+    hipLaunchKernelGGL(k_copy_jobs, dim3(bx, jobs.n), dim3(256), 0, st, jobs);
+}
+
 // test hook behind lprt_debug_sample_texture: the same fetch shade() makes
 __global__ void k_sample_texture(const Texture *textures, const float *lut, uint32_t handle, const float *uv, uint32_t n, float *rgba) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -9,7 +9,7 @@ data (geometry, BVH, materials) is replicated.
 Across frames the temporal history (SVGF colour/moment history, TAA history, frame counters) of a rank's HALO rows
 is not right -- those rows lack part of their own filter support -- so after each frame every rank sends the owned
 rows its neighbours hold as halo and receives its halo rows from their owners (`exchange_history`, point-to-point
-over xGMI: 2 x 68 rows x 65 B/pixel, about 17 MB per rank at 1080p fp32).  With that the sharded sequence equals the
+over xGMI: 2 x 68 rows x 49 B/pixel + 2 x 2 rows x 16 B/pixel of TAA history, about 13 MB per rank at 1080p fp32).  With that the sharded sequence equals the
 single-GPU sequence as long as reprojection moves a pixel by no more than `halo - 68` rows per frame (a static
 camera needs none; pass a larger `halo` for fast vertical motion).
 """
@@ -33,8 +33,14 @@ def window_rows(height, world_size, rank, halo=HALO_ROWS):
     return max(0, b - halo), min(height, e + halo)
 
 
+# The TAA history is only read within +-1 row of a pixel (jittered bilinear taps), so a rank needs it on 2 halo rows (plus
+# whatever vertical motion the halo was widened for), not on all 68
+TAA_ROWS = 2
+
+
 def history_transfers(height, world_size, halo=HALO_ROWS):
-    """[(src_rank, dst_rank, row_begin, row_end)]: rows src OWNS that dst holds as halo, in a fixed global order."""
+    """[(src_rank, dst_rank, row_begin, row_end)]: rows src OWNS that dst holds within `halo` rows of its strip, in a
+    fixed global order."""
     out = []
     for dst in range(world_size):
         wb, we = window_rows(height, world_size, dst, halo)
@@ -108,27 +114,36 @@ class ShardedFrame:
         return self.image
 
 
-    def exchange_history(self, renderer):
-        """After a frame: owned rows -> the neighbours that hold them as halo, halo rows <- their owners."""
+    def exchange_history(self, renderer, stream_ordered=False):
+        """After a frame: owned rows -> the neighbours that hold them as halo, halo rows <- their owners.  The SVGF
+        history travels for the whole halo, the TAA history for TAA_ROWS (+ motion margin) rows.  stream_ordered=True:
+        the renderer enqueues on torch's current stream and the transport is NCCL, which orders itself after that
+        stream — no host synchronisation is needed."""
         import torch.distributed as dist
+        from . import abi
         torch = self.torch
         if self.world == 1:
             return 0
         if self._hist is None:
-            row_bytes = renderer.history_row_bytes()
-            plan = [t for t in history_transfers(self.H, self.world, self.halo) if self.rank in t[:2]]
             staged = self.backend != "nccl"
             self._hist = []
-            for src, dst, b, e in plan:
-                dev = torch.empty((e - b) * row_bytes, dtype=torch.uint8, device=self.device)
-                host = torch.empty((e - b) * row_bytes, dtype=torch.uint8) if staged and dev.is_cuda else None
-                self._hist.append((src, dst, b, e, dev, host))
-        for src, dst, b, e, dev, host in self._hist:
+            taa_halo = min(self.halo, TAA_ROWS + max(0, self.halo - HALO_ROWS))
+            for groups, halo in ((abi.HIST_FILTER, self.halo), (abi.HIST_TAA, taa_halo)):
+                row_bytes = renderer.history_row_bytes(groups)
+                for src, dst, b, e in history_transfers(self.H, self.world, halo):
+                    if self.rank not in (src, dst) or not (self.win_begin <= b and e <= self.win_end):
+                        continue
+                    dev = torch.empty((e - b) * row_bytes, dtype=torch.uint8, device=self.device)
+                    host = torch.empty((e - b) * row_bytes, dtype=torch.uint8) if staged and dev.is_cuda else None
+                    self._hist.append((groups, src, dst, b, e, dev, host))
+        for groups, src, dst, b, e, dev, host in self._hist:
             if src == self.rank:
-                renderer.export_history_rows(b, e - b, dev.data_ptr())
-        renderer.synchronize()  # the exports run on the renderer's stream, the transport on torch's
+                renderer.export_history_rows(b, e - b, dev.data_ptr(), groups)
+        ordered = stream_ordered and self.backend == "nccl"
+        if not ordered:
+            renderer.synchronize()  # the exports run on the renderer's stream, the transport on torch's
         ops, moved = [], 0
-        for src, dst, b, e, dev, host in self._hist:
+        for groups, src, dst, b, e, dev, host in self._hist:
             if src == self.rank:
                 if host is not None:
                     host.copy_(dev)
@@ -138,15 +153,15 @@ class ShardedFrame:
             moved += dev.numel()
         for req in dist.batch_isend_irecv(ops):
             req.wait()
-        if self.torch.cuda.is_available() and str(self.device).startswith("cuda"):
+        if not ordered and self.torch.cuda.is_available() and str(self.device).startswith("cuda"):
             torch.cuda.synchronize()
-        for src, dst, b, e, dev, host in self._hist:
+        for groups, src, dst, b, e, dev, host in self._hist:
             if dst == self.rank:
                 if host is not None:
                     dev.copy_(host)
                     if dev.is_cuda:
                         torch.cuda.synchronize()
-                renderer.import_history_rows(b, e - b, dev.data_ptr())
+                renderer.import_history_rows(b, e - b, dev.data_ptr(), groups)
         return moved
 
 

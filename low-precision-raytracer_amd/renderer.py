@@ -46,9 +46,9 @@ SYMBOLS = [
     ("lprt_get_stage_counters", C.c_int, [_P, C.c_int, _P]),
     ("lprt_reset_counters", C.c_int, [_P]),
     ("lprt_set_output_target", C.c_int, [_P, _P, C.c_uint32, C.c_uint32]),
-    ("lprt_history_row_bytes", C.c_int, [_P, C.POINTER(C.c_size_t)]),
-    ("lprt_export_history_rows", C.c_int, [_P, C.c_uint32, C.c_uint32, _P]),
-    ("lprt_import_history_rows", C.c_int, [_P, C.c_uint32, C.c_uint32, _P]),
+    ("lprt_history_row_bytes", C.c_int, [_P, C.c_uint32, C.POINTER(C.c_size_t)]),
+    ("lprt_export_history_rows", C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32, _P]),
+    ("lprt_import_history_rows", C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32, _P]),
     ("lprt_debug_sample_texture", C.c_int, [_P, C.c_uint32, _P, C.c_uint32, _P]),
     ("lprt_debug_rng_states", C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_uint32, _P]),
     ("lprt_enable_stage_timing", C.c_int, [_P, C.c_int]),
@@ -222,16 +222,16 @@ class Renderer:
                     "lprt_set_output_target")
 
     # ---- sharded frames over several frames: temporal history of halo rows (dist.ShardedFrame.exchange_history) ----
-    def history_row_bytes(self):
+    def history_row_bytes(self, groups=abi.HIST_ALL):
         n = C.c_size_t()
-        self._check(self.L.lprt_history_row_bytes(self.h, C.byref(n)), "lprt_history_row_bytes")
+        self._check(self.L.lprt_history_row_bytes(self.h, groups, C.byref(n)), "lprt_history_row_bytes")
         return n.value
 
-    def export_history_rows(self, first_row, n_rows, dev_ptr):
-        self._check(self.L.lprt_export_history_rows(self.h, first_row, n_rows, C.c_void_p(int(dev_ptr))), "lprt_export_history_rows")
+    def export_history_rows(self, first_row, n_rows, dev_ptr, groups=abi.HIST_ALL):
+        self._check(self.L.lprt_export_history_rows(self.h, groups, first_row, n_rows, C.c_void_p(int(dev_ptr))), "lprt_export_history_rows")
 
-    def import_history_rows(self, first_row, n_rows, dev_ptr):
-        self._check(self.L.lprt_import_history_rows(self.h, first_row, n_rows, C.c_void_p(int(dev_ptr))), "lprt_import_history_rows")
+    def import_history_rows(self, first_row, n_rows, dev_ptr, groups=abi.HIST_ALL):
+        self._check(self.L.lprt_import_history_rows(self.h, groups, first_row, n_rows, C.c_void_p(int(dev_ptr))), "lprt_import_history_rows")
 
     def rng_states(self, seed, first, count):
         out = np.zeros((count, 6), dtype=np.uint32)

@@ -80,18 +80,18 @@ class _FakeRenderer:
             owned = self.f.begin <= r < self.f.end
             self.rows[r] = np.full(self.ROW_BYTES, (r * 7 + k) % 251 if owned else 255, dtype=np.uint8)
 
-    def history_row_bytes(self):
+    def history_row_bytes(self, groups=3):
         return self.ROW_BYTES
 
     def synchronize(self):
         pass
 
-    def export_history_rows(self, first, n, ptr):
+    def export_history_rows(self, first, n, ptr, groups=3):
         import ctypes
         buf = (ctypes.c_uint8 * (n * self.ROW_BYTES)).from_address(ptr)
         np.frombuffer(buf, dtype=np.uint8)[:] = np.concatenate([self.rows[first + i] for i in range(n)])
 
-    def import_history_rows(self, first, n, ptr):
+    def import_history_rows(self, first, n, ptr, groups=3):
         import ctypes
         buf = (ctypes.c_uint8 * (n * self.ROW_BYTES)).from_address(ptr)
         a = np.frombuffer(buf, dtype=np.uint8).reshape(n, self.ROW_BYTES)
