@@ -23,6 +23,56 @@
 
 namespace lprt {
 
+// A workgroup of the per-pixel kernels covers a 32x8-pixel tile and each wave an 8x8 block of it (instead of 256 / 64
+// pixels of one row): the rays of a wave start close together in both directions, so they walk the same part of the
+// BVH (atrium shadow rays 15.7 -> 11 ms per frame, Cornell frame 3.45 -> 3.35 ms).  Rows stay the unit of memory
+// layout: a wave touches 8 row segments of 8 pixels, a full 128-B line for the 16-B planes.
+template <typename T> LPRT_DEV uint32_t tile_pixel(const FrameDev<T> &fb) {
+    const uint32_t W = fb.win.W, R = fb.win.rows();
+    const uint32_t tiles_x = (W + 31u) / 32u;
+    const uint32_t tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t x = tx * 32u + wave * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
+    return (x < W && y < R) ? y * W + x : 0xffffffffu;
+}
+
+// Stable counting sort of the 256 work items of a workgroup by a small key (< 16 bins): returns the index of the thread
+// whose item this thread should process.  Items with equal keys end up in the same waves, so a wave walks rays that point
+// into the same octant (or start in the same part of the scene), and the items without work (key = n_bins - 1) gather in
+// the last waves, which then leave at once.  Per-pixel results do not depend on which thread computes them.
+LPRT_DEV uint32_t block_sort_order(uint32_t key, uint32_t n_bins) {
+    __shared__ uint16_t s_cnt[16][4];
+    __shared__ uint16_t s_order[256];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint32_t below_in_wave = 0;
+    for (uint32_t b = 0; b < n_bins; b++) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(key == b);
+        if (lane == 0)
+            s_cnt[b][wave] = (uint16_t)__builtin_popcountll(m);
+        if (key == b)
+            below_in_wave = (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+    }
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t b = 0; b < n_bins; b++)
+        for (uint32_t w = 0; w < 4; w++)
+            if (b < key || (b == key && w < wave))
+                base += s_cnt[b][w];
+    s_order[base + below_in_wave] = (uint16_t)threadIdx.x;
+    __syncthreads();
+    return s_order[threadIdx.x];
+}
+// pixel of work item `item` (0..255) of this workgroup's 32x8 tile
+template <typename T> LPRT_DEV uint32_t tile_pixel_of(const FrameDev<T> &fb, uint32_t item) {
+    const uint32_t W = fb.win.W, R = fb.win.rows();
+    const uint32_t tiles_x = (W + 31u) / 32u;
+    const uint32_t tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const uint32_t wave = item >> 6, lane = item & 63u;
+    const uint32_t x = tx * 32u + wave * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
+    return (x < W && y < R) ? y * W + x : 0xffffffffu;
+}
+template <typename T> static inline dim3 tile_grid(const FrameDev<T> &fb) { return dim3(((fb.win.W + 31u) / 32u) * ((fb.win.rows() + 7u) / 8u)); }
+
 template <typename T> LPRT_DEV V3<T> ld3(const T *p) { return mk3(p[0], p[1], p[2]); }
 LPRT_DEV uint32_t pack_rgba8(uint32_t r, uint32_t g, uint32_t b, uint32_t a) { return r | (g << 8) | (b << 16) | (a << 24); }
 
@@ -56,7 +106,7 @@ template <typename T> LPRT_DEV HitAttr<T> interpolate_hit(const SceneDev<T> &sc,
 // ---- G2: fill_gbuffer_in_cuda (cuda.hpp:950-1012) ---------------------------------------------------------
 template <typename T, bool COUNT>
 __global__ void __launch_bounds__(256, LPRT_CLOSEST_WAVES) k_fill_gbuffer(SceneDev<T> sc, FrameDev<T> fb, Counters *counters) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t p = tile_pixel(fb);
     Cnt<COUNT> cnt;
     if (p < fb.win.npix()) {
         const uint32_t x = p % fb.win.W, y = fb.win.row_begin + p / fb.win.W;
@@ -395,7 +445,7 @@ LPRT_DEV void shade_and_store(const SceneDev<T> &sc, const FrameDev<T> &fb, uint
 
 template <typename T, bool NO_GI>
 __global__ void __launch_bounds__(256) k_shade(SceneDev<T> sc, FrameDev<T> fb, uint32_t rng_d, uint32_t sample) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t p = tile_pixel(fb);
     if (p >= fb.win.npix())
         return;
     const T zero = (T)0;
@@ -433,7 +483,7 @@ struct ComposeArgs {
 };
 template <typename T, bool FIRST, bool COMPOSE, bool COUNT>
 __global__ void __launch_bounds__(256, LPRT_ANYHIT_WAVES) k_trace_di(SceneDev<T> sc, FrameDev<T> fb, ComposeArgs ca, Counters *counters) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t p = tile_pixel(fb);
     const uint32_t npix = fb.win.npix();
     Cnt<COUNT> cnt;
     if (p < npix) {
@@ -508,7 +558,15 @@ __global__ void __launch_bounds__(256, LPRT_ANYHIT_WAVES) k_trace_di(SceneDev<T>
 // traversal result is live here when the traversal ends, so the record stays in registers.
 template <typename T, bool COUNT>
 __global__ void __launch_bounds__(256, LPRT_CLOSEST_WAVES) k_trace_gi(SceneDev<T> sc, FrameDev<T> fb, Counters *counters) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t p = tile_pixel(fb);
+    {
+        uint32_t key = 8u; // no GI ray
+        if (p < fb.win.npix() && fb.gi_valid[p]) {
+            const V4<T> d = fb.gi_direction[p];
+            key = ((float)d.x < 0.f ? 1u : 0u) | ((float)d.y < 0.f ? 2u : 0u) | ((float)d.z < 0.f ? 4u : 0u);
+        }
+        p = tile_pixel_of(fb, block_sort_order(key, 9u));
+    }
     Cnt<COUNT> cnt;
     if (p < fb.win.npix()) {
         const T zero = (T)0;
@@ -548,15 +606,15 @@ static inline dim3 grid_for(uint32_t n) { return dim3((n + 255) / 256); }
 
 template <typename T> void launch_fill_gbuffer(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, Counters *c) {
     if (c)
-        hipLaunchKernelGGL((k_fill_gbuffer<T, true>), grid_for(fb.win.npix()), dim3(256), 0, st, sc, fb, c);
+        hipLaunchKernelGGL((k_fill_gbuffer<T, true>), tile_grid(fb), dim3(256), 0, st, sc, fb, c);
     else
-        hipLaunchKernelGGL((k_fill_gbuffer<T, false>), grid_for(fb.win.npix()), dim3(256), 0, st, sc, fb, c);
+        hipLaunchKernelGGL((k_fill_gbuffer<T, false>), tile_grid(fb), dim3(256), 0, st, sc, fb, c);
 }
 template <typename T> void launch_temporal_map(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, uint32_t rng_d) {
     hipLaunchKernelGGL(k_temporal_map<T>, grid_for(fb.win.npix()), dim3(256), 0, st, sc, fb, first ? 1 : 0, rng_d);
 }
 template <typename T> void launch_shade(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool no_gi, uint32_t rng_d, uint32_t sample) {
-    dim3 g = grid_for(fb.win.npix()), b(256);
+    dim3 g = tile_grid(fb), b(256);
     if (!no_gi)
         hipLaunchKernelGGL((k_shade<T, false>), g, b, 0, st, sc, fb, rng_d, sample);
     else
@@ -566,7 +624,7 @@ template <typename T> void launch_shade(hipStream_t st, const SceneDev<T> &sc, c
 template <typename T>
 void launch_trace_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, bool gi_on, bool add_direct, uint32_t sample, uint32_t spp,
                      Counters *c) {
-    dim3 g = grid_for(fb.win.npix()), b(256);
+    dim3 g = tile_grid(fb), b(256);
     ComposeArgs ca{gi_on ? 1 : 0, add_direct ? 1 : 0, sample, spp};
     if (first && gi_on) {
         if (c)
@@ -587,9 +645,9 @@ void launch_trace_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &f
 }
 template <typename T> void launch_trace_gi(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, Counters *c) {
     if (c)
-        hipLaunchKernelGGL((k_trace_gi<T, true>), grid_for(fb.win.npix()), dim3(256), 0, st, sc, fb, c);
+        hipLaunchKernelGGL((k_trace_gi<T, true>), tile_grid(fb), dim3(256), 0, st, sc, fb, c);
     else
-        hipLaunchKernelGGL((k_trace_gi<T, false>), grid_for(fb.win.npix()), dim3(256), 0, st, sc, fb, c);
+        hipLaunchKernelGGL((k_trace_gi<T, false>), tile_grid(fb), dim3(256), 0, st, sc, fb, c);
 }
 
 #define INST(T)                                                                                                        \
