@@ -27,12 +27,20 @@ namespace lprt {
 // pixels of one row): the rays of a wave start close together in both directions, so they walk the same part of the
 // BVH (atrium shadow rays 15.7 -> 11 ms per frame, Cornell frame 3.45 -> 3.35 ms).  Rows stay the unit of memory
 // layout: a wave touches 8 row segments of 8 pixels, a full 128-B line for the 16-B planes.
+#ifndef LPRT_TILE_W
+#define LPRT_TILE_W 32u
+#define LPRT_TILE_H 8u
+#define LPRT_WAVE_W 8u
+#define LPRT_WAVE_H 8u
+#endif
+static_assert(LPRT_WAVE_W * LPRT_WAVE_H == 64u && (LPRT_TILE_W / LPRT_WAVE_W) * (LPRT_TILE_H / LPRT_WAVE_H) == 4u, "a workgroup is four waves");
 template <typename T> LPRT_DEV uint32_t tile_pixel(const FrameDev<T> &fb) {
     const uint32_t W = fb.win.W, R = fb.win.rows();
-    const uint32_t tiles_x = (W + 31u) / 32u;
+    const uint32_t tiles_x = (W + LPRT_TILE_W - 1u) / LPRT_TILE_W;
     const uint32_t tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t x = tx * 32u + wave * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
+    const uint32_t wx = wave % (LPRT_TILE_W / LPRT_WAVE_W), wy = wave / (LPRT_TILE_W / LPRT_WAVE_W);
+    const uint32_t x = tx * LPRT_TILE_W + wx * LPRT_WAVE_W + lane % LPRT_WAVE_W, y = ty * LPRT_TILE_H + wy * LPRT_WAVE_H + lane / LPRT_WAVE_W;
     return (x < W && y < R) ? y * W + x : 0xffffffffu;
 }
 
@@ -65,13 +73,14 @@ LPRT_DEV uint32_t block_sort_order(uint32_t key, uint32_t n_bins) {
 // pixel of work item `item` (0..255) of this workgroup's 32x8 tile
 template <typename T> LPRT_DEV uint32_t tile_pixel_of(const FrameDev<T> &fb, uint32_t item) {
     const uint32_t W = fb.win.W, R = fb.win.rows();
-    const uint32_t tiles_x = (W + 31u) / 32u;
+    const uint32_t tiles_x = (W + LPRT_TILE_W - 1u) / LPRT_TILE_W;
     const uint32_t tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
     const uint32_t wave = item >> 6, lane = item & 63u;
-    const uint32_t x = tx * 32u + wave * 8u + (lane & 7u), y = ty * 8u + (lane >> 3);
+    const uint32_t wx = wave % (LPRT_TILE_W / LPRT_WAVE_W), wy = wave / (LPRT_TILE_W / LPRT_WAVE_W);
+    const uint32_t x = tx * LPRT_TILE_W + wx * LPRT_WAVE_W + lane % LPRT_WAVE_W, y = ty * LPRT_TILE_H + wy * LPRT_WAVE_H + lane / LPRT_WAVE_W;
     return (x < W && y < R) ? y * W + x : 0xffffffffu;
 }
-template <typename T> static inline dim3 tile_grid(const FrameDev<T> &fb) { return dim3(((fb.win.W + 31u) / 32u) * ((fb.win.rows() + 7u) / 8u)); }
+template <typename T> static inline dim3 tile_grid(const FrameDev<T> &fb) { return dim3(((fb.win.W + LPRT_TILE_W - 1u) / LPRT_TILE_W) * ((fb.win.rows() + LPRT_TILE_H - 1u) / LPRT_TILE_H)); }
 
 template <typename T> LPRT_DEV V3<T> ld3(const T *p) { return mk3(p[0], p[1], p[2]); }
 LPRT_DEV uint32_t pack_rgba8(uint32_t r, uint32_t g, uint32_t b, uint32_t a) { return r | (g << 8) | (b << 16) | (a << 24); }
