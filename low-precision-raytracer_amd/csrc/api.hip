@@ -691,7 +691,7 @@ template <typename F> static int guarded(lprt_ctx *ctx, F &&f) {
 
 extern "C" {
 
-const char *lprt_version(void) { return "lprt-hip 0.1 (gfx950)"; }
+const char *lprt_version(void) { return "lprt-hip 0.2 (gfx950)"; }
 
 int lprt_create(lprt_ctx **out, int device, uint32_t width, uint32_t height, uint32_t row_begin, uint32_t row_end,
                 lprt_precision precision) {
