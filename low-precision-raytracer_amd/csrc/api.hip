@@ -236,6 +236,9 @@ template <typename T> struct Impl : CtxBase {
             fb.lobe[l].cv_b = carve<V4<T>>(off, n);
             fb.lobe[l].cv_c = carve<V4<T>>(off, n);
             fb.lobe[l].illum = carve<T>(off, n);
+            fb.lobe[l].var_a = carve<T>(off, n);
+            fb.lobe[l].var_b = carve<T>(off, n);
+            fb.lobe[l].var_c = carve<T>(off, n);
             fb.lobe[l].miu1_hist = carve<T>(off, n);
             fb.lobe[l].miu2_hist = carve<T>(off, n);
             fb.lobe[l].miu1_cur = carve<T>(off, n);

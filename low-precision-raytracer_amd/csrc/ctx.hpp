@@ -67,6 +67,8 @@ template <typename T> struct SvgfLobe {
     V4<T> *cv_b;   // color_history (level-1 output; next frame's temporal history) + var
     V4<T> *cv_c;   // color_buffer + var
     T *illum;      // illum_buffer
+    T *var_a, *var_b, *var_c; // the .w of cv_a/b/c once more as planes of their own: the 3x3 variance prefilter of the
+                              // a-trous levels reads 9 image neighbours, and 4-B loads cost a quarter of the cache lines
     T *miu1_hist, *miu2_hist; // miu1_1 / miu2_1
     T *miu1_cur, *miu2_cur;   // miu1_2 / miu2_2
 };

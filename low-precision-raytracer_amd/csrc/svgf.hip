@@ -232,7 +232,9 @@ __global__ void __launch_bounds__(256) k_moments(FrameDev<T> fb, T moments_w) {
     for (int l = 0; l < 2; l++) {
         fb.lobe[l].miu1_cur[p] = miu1[l];
         fb.lobe[l].miu2_cur[p] = miu2[l];
-        fb.lobe[l].cv_c[p].w = miu2[l] - miu1[l] * miu1[l]; // variance, not clamped at 0
+        const T var = miu2[l] - miu1[l] * miu1[l]; // variance, not clamped at 0
+        fb.lobe[l].cv_c[p].w = var;
+        fb.lobe[l].var_c[p] = var;
     }
 }
 
@@ -246,7 +248,8 @@ __global__ void __launch_bounds__(256) k_moments(FrameDev<T> fb, T moments_w) {
 #endif
 constexpr int WV_BX = 64, WV_BY = 4;
 template <typename T, int STRIDE>
-__global__ void __launch_bounds__(256) k_wavelet(FrameDev<T> fb, const V4<T> *in0, V4<T> *out0, const V4<T> *in1, V4<T> *out1) {
+__global__ void __launch_bounds__(256) k_wavelet(FrameDev<T> fb, const V4<T> *in0, V4<T> *out0, const V4<T> *in1, V4<T> *out1, const T *vin0, T *vout0,
+                                                 const T *vin1, T *vout1) {
     constexpr int TW = WV_BX + 4 * STRIDE, TH = WV_BY + 4;
     // fp32 at strides 8 and 16: four staged planes (56 B per texel) leave room for only 3 / 2 workgroups per CU, and
     // the kernel is latency-bound; there the colour planes are read straight from L1/L2 (rows are still contiguous
@@ -296,8 +299,8 @@ __global__ void __launch_bounds__(256) k_wavelet(FrameDev<T> fb, const V4<T> *in
                 continue;
             T g = gk[i < 0 ? -i : i] * gk[j < 0 ? -j : j];
             uint32_t q = (uint32_t)(qy * W + qx);
-            sg[0] = sg[0] + g * in[0][q].w;
-            sg[1] = sg[1] + g * in[1][q].w;
+            sg[0] = sg[0] + g * vin0[q];
+            sg[1] = sg[1] + g * vin1[q];
             gw = gw + g;
         }
     }
@@ -366,6 +369,7 @@ __global__ void __launch_bounds__(256) k_wavelet(FrameDev<T> fb, const V4<T> *in
         if (!tfinite(nv))
             nv = centre.w;
         out[l][p] = mk4(nc.x, nc.y, nc.z, nv);
+        (l == 0 ? vout0 : vout1)[p] = nv;
     }
 }
 
@@ -462,11 +466,11 @@ template <typename T> void launch_wavelet(hipStream_t st, const FrameDev<T> &fb,
     const dim3 g((fb.win.W + WV_BX - 1) / WV_BX, stride * ((lattice_rows + WV_BY - 1) / WV_BY)), b(256);
     const SvgfLobe<T> &a = fb.lobe[0], &w = fb.lobe[1];
     switch (level) {
-    case 0: hipLaunchKernelGGL((k_wavelet<T, 1>), g, b, 0, st, fb, a.cv_c, a.cv_b, w.cv_c, w.cv_b); break;
-    case 1: hipLaunchKernelGGL((k_wavelet<T, 2>), g, b, 0, st, fb, a.cv_b, a.cv_a, w.cv_b, w.cv_a); break;
-    case 2: hipLaunchKernelGGL((k_wavelet<T, 4>), g, b, 0, st, fb, a.cv_a, a.cv_c, w.cv_a, w.cv_c); break;
-    case 3: hipLaunchKernelGGL((k_wavelet<T, 8>), g, b, 0, st, fb, a.cv_c, a.cv_a, w.cv_c, w.cv_a); break;
-    default: hipLaunchKernelGGL((k_wavelet<T, 16>), g, b, 0, st, fb, a.cv_a, a.cv_c, w.cv_a, w.cv_c); break;
+    case 0: hipLaunchKernelGGL((k_wavelet<T, 1>), g, b, 0, st, fb, a.cv_c, a.cv_b, w.cv_c, w.cv_b, a.var_c, a.var_b, w.var_c, w.var_b); break;
+    case 1: hipLaunchKernelGGL((k_wavelet<T, 2>), g, b, 0, st, fb, a.cv_b, a.cv_a, w.cv_b, w.cv_a, a.var_b, a.var_a, w.var_b, w.var_a); break;
+    case 2: hipLaunchKernelGGL((k_wavelet<T, 4>), g, b, 0, st, fb, a.cv_a, a.cv_c, w.cv_a, w.cv_c, a.var_a, a.var_c, w.var_a, w.var_c); break;
+    case 3: hipLaunchKernelGGL((k_wavelet<T, 8>), g, b, 0, st, fb, a.cv_c, a.cv_a, w.cv_c, w.cv_a, a.var_c, a.var_a, w.var_c, w.var_a); break;
+    default: hipLaunchKernelGGL((k_wavelet<T, 16>), g, b, 0, st, fb, a.cv_a, a.cv_c, w.cv_a, w.cv_c, a.var_a, a.var_c, w.var_a, w.var_c); break;
     }
 }
 template <typename T>
