@@ -119,11 +119,7 @@ __global__ void k_make_objrecs(const ObjSlot<T> *slots, const ObjConst<T> *objec
         r.hi[k] = slot.hi[k];
     }
     r.W2L = oc.W2L;
-    bool ident = true;
-    for (int k = 0; k < 16; k++)
-        ident = ident && (oc.W2L.m[k] == ((k % 5 == 0) ? (T)1 : (T)0));
-    r.identity = ident ? 1u : 0u;
-    r.pad[0] = r.pad[1] = r.pad[2] = 0;
+    r.pad[0] = r.pad[1] = 0;
     r.inscene_objid = slot.inscene_objid;
     r.vao_index = oc.objectid;
     BlasInfo bi{};

@@ -57,8 +57,7 @@ template <typename T> struct alignas(16) ObjRec {
     T root_lo[3], root_hi[3]; // BLAS root box (object space)
     M4<T> W2L;
     uint32_t inscene_objid, vao_index, n_tris, depth, tri_base, inner_base;
-    uint32_t identity; // W2L is exactly the identity: the local ray is the world ray (x*1 + y*0 + ... is exact)
-    uint32_t pad[3];
+    uint32_t pad[2];
 };
 // CUDAObjectConstantData<DataT> (memory.hpp:279-301)
 template <typename T> struct alignas(16) ObjConst {
