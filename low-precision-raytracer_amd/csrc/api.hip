@@ -166,6 +166,8 @@ template <typename T> struct Impl : CtxBase {
     uint32_t n_materials = 0, n_objects = 0, n_lights = 0;
     lprt_camera camera{};
     lprt_skybox skybox{};
+    PinnedStage h_scene[2];
+    int h_scene_next = 0;
     float w2c[16] = {};
     bool have_scene = false;
 
@@ -478,12 +480,25 @@ template <typename T> struct Impl : CtxBase {
         d_objects.reserve(sizeof(ObjConst<T>) * (size_t)std::max(n, 1u));
         d_lights32.reserve(sizeof(lprt_light) * (size_t)std::max(nl, 1u));
         d_lights.reserve(sizeof(LightT<T>) * (size_t)std::max(nl, 1u));
-        if (n)
-            LPRT_HIP(hipMemcpyAsync(d_objects32.ptr, obj, sizeof(lprt_object) * (size_t)n, hipMemcpyHostToDevice, stream));
-        if (nl)
-            LPRT_HIP(hipMemcpyAsync(d_lights32.ptr, lights, sizeof(lprt_light) * (size_t)nl, hipMemcpyHostToDevice, stream));
-        stage(LPRT_STAGE_BUILD_TLAS, [&] { tlas.build(stream, aabbs, n); });
-        LPRT_HIP(hipStreamSynchronize(stream)); // the caller's arrays may go away after return (pageable copies)
+        // The caller's arrays may go away after return, and a per-frame call must not stall the stream: they are copied
+        // into one of two pinned staging buffers (reused only after the copies issued from it have completed) and go to
+        // the device from there, asynchronously.
+        const size_t b_obj = sizeof(lprt_object) * (size_t)n, b_light = sizeof(lprt_light) * (size_t)nl, b_box = sizeof(lprt_aabb) * (size_t)n;
+        PinnedStage &hs = h_scene[h_scene_next];
+        h_scene_next ^= 1;
+        hs.acquire(b_obj + b_light + b_box + 16);
+        char *hp = static_cast<char *>(hs.ptr);
+        if (n) {
+            std::memcpy(hp, obj, b_obj);
+            std::memcpy(hp + b_obj + b_light, aabbs, b_box);
+            LPRT_HIP(hipMemcpyAsync(d_objects32.ptr, hp, b_obj, hipMemcpyHostToDevice, stream));
+        }
+        if (nl) {
+            std::memcpy(hp + b_obj, lights, b_light);
+            LPRT_HIP(hipMemcpyAsync(d_lights32.ptr, hp + b_obj, b_light, hipMemcpyHostToDevice, stream));
+        }
+        stage(LPRT_STAGE_BUILD_TLAS, [&] { tlas.build(stream, reinterpret_cast<const lprt_aabb *>(hp + b_obj + b_light), n); });
+        hs.release(stream);
         launch_convert_objects<T>(stream, d_objects32.as<lprt_object>(), d_objects.as<ObjConst<T>>(), n);
         launch_convert_lights<T>(stream, d_lights32.as<lprt_light>(), d_lights.as<LightT<T>>(), nl);
         camera = *cam;

@@ -47,6 +47,43 @@ struct DevBuf {
     DevBuf &operator=(const DevBuf &) = delete;
 };
 
+// pinned host staging for small per-frame uploads: acquire() waits for the copies issued from it last time (normally long
+// finished), release() marks the point on the stream after which it may be overwritten
+struct PinnedStage {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    hipEvent_t ev = nullptr;
+    bool in_flight = false;
+    void acquire(size_t n) {
+        if (in_flight) {
+            LPRT_HIP(hipEventSynchronize(ev));
+            in_flight = false;
+        }
+        if (n > bytes) {
+            if (ptr)
+                (void)hipHostFree(ptr);
+            ptr = nullptr;
+            LPRT_HIP(hipHostMalloc(&ptr, n, hipHostMallocDefault));
+            bytes = n;
+        }
+    }
+    void release(hipStream_t st) {
+        if (!ev)
+            LPRT_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        LPRT_HIP(hipEventRecord(ev, st));
+        in_flight = true;
+    }
+    ~PinnedStage() {
+        if (ev)
+            (void)hipEventDestroy(ev);
+        if (ptr)
+            (void)hipHostFree(ptr);
+    }
+    PinnedStage() = default;
+    PinnedStage(const PinnedStage &) = delete;
+    PinnedStage &operator=(const PinnedStage &) = delete;
+};
+
 struct StageTimer {
     bool enabled = false;
     uint32_t mask = 0xffffffffu; // bit s set: stage s is bracketed by events
