@@ -161,7 +161,7 @@ struct CtxBase {
 template <typename T> struct Impl : CtxBase {
     GeometryStore<T> geo;
     TlasStore<T> tlas;
-    DevBuf d_materials32, d_materials, d_objects32, d_objects, d_lights32, d_lights, d_counters, d_rays, d_hits, d_objrecs;
+    DevBuf d_materials32, d_materials, d_scene32, d_objects, d_lights, d_counters, d_rays, d_hits, d_objrecs;
     bool objrecs_dirty = true;
     uint32_t n_materials = 0, n_objects = 0, n_lights = 0;
     lprt_camera camera{};
@@ -476,31 +476,42 @@ template <typename T> struct Impl : CtxBase {
                    const lprt_camera *cam, const float *W2C, const lprt_skybox *sky) override {
         n_objects = n;
         n_lights = nl;
-        d_objects32.reserve(sizeof(lprt_object) * (size_t)std::max(n, 1u));
-        d_objects.reserve(sizeof(ObjConst<T>) * (size_t)std::max(n, 1u));
-        d_lights32.reserve(sizeof(lprt_light) * (size_t)std::max(nl, 1u));
-        d_lights.reserve(sizeof(LightT<T>) * (size_t)std::max(nl, 1u));
-        // The caller's arrays may go away after return, and a per-frame call must not stall the stream: they are copied
-        // into one of two pinned staging buffers (reused only after the copies issued from it have completed) and go to
-        // the device from there, asynchronously.
+        // The caller's arrays may go away after return, and a per-frame call must not stall the stream: objects, lights and
+        // world boxes are copied into one of two pinned staging buffers (reused only after the copy issued from it has
+        // completed), go to the device in ONE transfer, and one kernel builds the TLAS, converts lights and instance
+        // constants to DataT and gathers the per-slot object records.
         const size_t b_obj = sizeof(lprt_object) * (size_t)n, b_light = sizeof(lprt_light) * (size_t)nl, b_box = sizeof(lprt_aabb) * (size_t)n;
+        const size_t total = b_obj + b_light + b_box;
+        d_scene32.reserve(std::max<size_t>(total, 16));
+        d_objects.reserve(sizeof(ObjConst<T>) * (size_t)std::max(n, 1u));
+        d_lights.reserve(sizeof(LightT<T>) * (size_t)std::max(nl, 1u));
+        d_objrecs.reserve(sizeof(ObjRec<T>) * (size_t)std::max(n, 1u));
         PinnedStage &hs = h_scene[h_scene_next];
         h_scene_next ^= 1;
-        hs.acquire(b_obj + b_light + b_box + 16);
+        hs.acquire(total + 16);
         char *hp = static_cast<char *>(hs.ptr);
         if (n) {
             std::memcpy(hp, obj, b_obj);
             std::memcpy(hp + b_obj + b_light, aabbs, b_box);
-            LPRT_HIP(hipMemcpyAsync(d_objects32.ptr, hp, b_obj, hipMemcpyHostToDevice, stream));
         }
-        if (nl) {
+        if (nl)
             std::memcpy(hp + b_obj, lights, b_light);
-            LPRT_HIP(hipMemcpyAsync(d_lights32.ptr, hp + b_obj, b_light, hipMemcpyHostToDevice, stream));
-        }
-        stage(LPRT_STAGE_BUILD_TLAS, [&] { tlas.build(stream, reinterpret_cast<const lprt_aabb *>(hp + b_obj + b_light), n); });
+        if (total)
+            LPRT_HIP(hipMemcpyAsync(d_scene32.ptr, hp, total, hipMemcpyHostToDevice, stream));
         hs.release(stream);
-        launch_convert_objects<T>(stream, d_objects32.as<lprt_object>(), d_objects.as<ObjConst<T>>(), n);
-        launch_convert_lights<T>(stream, d_lights32.as<lprt_light>(), d_lights.as<LightT<T>>(), nl);
+        char *dp = static_cast<char *>(d_scene32.ptr);
+        SceneSetup<T> su{};
+        su.objects32 = reinterpret_cast<const lprt_object *>(dp);
+        su.objects = d_objects.as<ObjConst<T>>();
+        su.n_objects = n;
+        su.lights32 = reinterpret_cast<const lprt_light *>(dp + b_obj);
+        su.lights = d_lights.as<LightT<T>>();
+        su.n_lights = nl;
+        su.blas = geo.built ? geo.d_blas.template as<BlasInfo>() : nullptr;
+        su.roots = geo.d_roots.template as<T>();
+        su.n_vaos = geo.n_vaos;
+        su.objrecs = d_objrecs.as<ObjRec<T>>();
+        stage(LPRT_STAGE_BUILD_TLAS, [&] { tlas.build(stream, reinterpret_cast<const lprt_aabb *>(dp + b_obj + b_light), n, su); });
         camera = *cam;
         std::memcpy(w2c, W2C, sizeof(w2c));
         if (sky && sky->valid) {
@@ -511,7 +522,7 @@ template <typename T> struct Impl : CtxBase {
             skybox = lprt_skybox{};
         }
         have_scene = true;
-        objrecs_dirty = true;
+        objrecs_dirty = !geo.built; // made by the set-up kernel unless the BLAS set does not exist yet
     }
     SceneDev<T> scene_dev() const {
         SceneDev<T> sc{};

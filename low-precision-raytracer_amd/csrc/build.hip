@@ -9,6 +9,7 @@
 // B2 replaces SceneBVH::update (rt/trace/scene_bvh.hpp:50-133), rebuilt per frame on the CPU, by a
 //    single-workgroup kernel (LDS bitonic sort + the same tree).
 #include "build.hpp"
+#include "scene_dev.hpp"
 #include <cstdlib>
 #include <string>
 
@@ -620,7 +621,21 @@ template <typename T> __global__ void k_inner_level(const BlasInfo *blas, uint32
 constexpr int TLAS_MAX = 1024;
 template <typename T>
 __global__ void __launch_bounds__(256) k_build_tlas(const lprt_aabb *aabbs, uint32_t n, uint32_t D, ObjSlot<T> *slots,
-                                                    uint32_t *leaf_words, InnerNode<T> *inner, T *root) {
+                                                    uint32_t *leaf_words, InnerNode<T> *inner, T *root, SceneSetup<T> su) {
+    // The rest of lprt_set_scene rides along (one dispatch per frame instead of four): DataT copies of the lights and the
+    // instance constants first, the per-slot object records after the slots exist.
+    for (uint32_t i = threadIdx.x; i < su.n_lights; i += 256) {
+        LightT<T> l;
+        convert_light(su.lights32[i], l);
+        su.lights[i] = l;
+    }
+    for (uint32_t i = threadIdx.x; i < su.n_objects; i += 256) {
+        ObjConst<T> o;
+        convert_object(su.objects32[i], o);
+        su.objects[i] = o;
+    }
+    if (n == 0)
+        return;
     __shared__ unsigned long long keys[TLAS_MAX];
     __shared__ float red[6][256];
     __shared__ float lvl_lo[TLAS_MAX][3], lvl_hi[TLAS_MAX][3]; // boxes of the level being reduced
@@ -747,6 +762,15 @@ __global__ void __launch_bounds__(256) k_build_tlas(const lprt_aabb *aabbs, uint
                 }
         }
         __syncthreads();
+    }
+    if (su.blas) { // slots and instance constants were written by this workgroup: make them visible, then gather
+        __threadfence_block();
+        __syncthreads();
+        for (uint32_t s = threadIdx.x; s < n; s += 256) {
+            ObjRec<T> r;
+            make_objrec(slots[s], su.objects[slots[s].inscene_objid], su.blas, su.roots, su.n_vaos, r);
+            su.objrecs[s] = r;
+        }
     }
 }
 
@@ -966,19 +990,16 @@ template <typename T> void GeometryStore<T>::build_blas(hipStream_t st) {
     built = true;
 }
 
-template <typename T> void TlasStore<T>::build(hipStream_t st, const lprt_aabb *aabbs, uint32_t n) {
+// aabbs: DEVICE pointer (the caller has already enqueued the copy on st)
+template <typename T> void TlasStore<T>::build(hipStream_t st, const lprt_aabb *aabbs, uint32_t n, const SceneSetup<T> &su) {
     n_objects = n;
     depth = n ? floor_log2(n) : 0;
-    d_aabbs.reserve(sizeof(lprt_aabb) * (size_t)std::max(n, 1u));
     d_slots.reserve(sizeof(ObjSlot<T>) * (size_t)std::max(n, 1u));
     d_leaf.reserve(sizeof(uint32_t) * (size_t)(1u << depth));
     d_inner.reserve(sizeof(InnerNode<T>) * (size_t)std::max((1u << depth) - 1, 1u));
     d_root.reserve(sizeof(T) * 6);
-    if (n == 0)
-        return;
-    LPRT_HIP(hipMemcpyAsync(d_aabbs.ptr, aabbs, sizeof(lprt_aabb) * (size_t)n, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_build_tlas<T>, dim3(1), dim3(256), 0, st, d_aabbs.as<lprt_aabb>(), n, depth, d_slots.as<ObjSlot<T>>(),
-                       d_leaf.as<uint32_t>(), d_inner.as<InnerNode<T>>(), d_root.as<T>());
+    hipLaunchKernelGGL(k_build_tlas<T>, dim3(1), dim3(256), 0, st, aabbs, n, depth, d_slots.as<ObjSlot<T>>(), d_leaf.as<uint32_t>(),
+                       d_inner.as<InnerNode<T>>(), d_root.as<T>(), su);
     LPRT_HIP(hipGetLastError());
 }
 

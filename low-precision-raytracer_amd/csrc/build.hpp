@@ -1,6 +1,7 @@
 // Owners of the static geometry / BLAS set and of the per-frame TLAS.
 #pragma once
 #include "ctx.hpp"
+#include "scene_dev.hpp"
 #include <algorithm>
 
 namespace lprt {
@@ -25,8 +26,8 @@ template <typename T> struct GeometryStore {
 
 template <typename T> struct TlasStore {
     uint32_t n_objects = 0, depth = 0;
-    DevBuf d_aabbs, d_slots, d_leaf, d_inner, d_root;
-    void build(hipStream_t st, const lprt_aabb *aabbs, uint32_t n);
+    DevBuf d_slots, d_leaf, d_inner, d_root;
+    void build(hipStream_t st, const lprt_aabb *aabbs_dev, uint32_t n, const SceneSetup<T> &setup);
 };
 
 } // namespace lprt

@@ -2,6 +2,7 @@
 // GI rays (TG) and shadow rays (TD).
 #include "kernels.hpp"
 #include <algorithm>
+#include "scene_dev.hpp"
 #include "shade.hpp"
 #include "trace.hpp"
 
@@ -58,13 +59,7 @@ template <typename T> __global__ void k_convert_objects(const lprt_object *in, O
     if (i >= n)
         return;
     ObjConst<T> o;
-    for (int k = 0; k < 16; k++) {
-        o.L2W.m[k] = cvt<T>(in[i].transform_L2W[k]);
-        o.W2L.m[k] = cvt<T>(in[i].transform_W2L[k]);
-    }
-    o.materialid = in[i].materialid;
-    o.objectid = in[i].objectid;
-    o.pad[0] = o.pad[1] = 0;
+    convert_object(in[i], o);
     out[i] = o;
 }
 template <typename T> __global__ void k_convert_materials(const lprt_material *in, MaterialT<T> *out, uint32_t n) {
@@ -89,12 +84,7 @@ template <typename T> __global__ void k_convert_lights(const lprt_light *in, Lig
     if (i >= n)
         return;
     LightT<T> l;
-    for (int k = 0; k < 3; k++) {
-        l.direction[k] = cvt<T>(in[i].direction[k]);
-        l.intensity[k] = cvt<T>(in[i].intensity[k]);
-        l.position[k] = cvt<T>(in[i].position[k]);
-    }
-    l.type = in[i].type;
+    convert_light(in[i], l);
     out[i] = l;
 }
 template <typename T> __global__ void k_convert_mat4(const float *in, M4<T> *out, uint32_t n) {
@@ -111,28 +101,8 @@ __global__ void k_make_objrecs(const ObjSlot<T> *slots, const ObjConst<T> *objec
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n)
         return;
-    const ObjSlot<T> slot = slots[s];
-    const ObjConst<T> oc = objects[slot.inscene_objid];
     ObjRec<T> r;
-    for (int k = 0; k < 3; k++) {
-        r.lo[k] = slot.lo[k];
-        r.hi[k] = slot.hi[k];
-    }
-    r.W2L = oc.W2L;
-    r.pad[0] = r.pad[1] = 0;
-    r.inscene_objid = slot.inscene_objid;
-    r.vao_index = oc.objectid;
-    BlasInfo bi{};
-    if (oc.objectid < n_vaos)
-        bi = blas[oc.objectid];
-    r.n_tris = bi.n_tris;
-    r.depth = bi.depth;
-    r.tri_base = bi.tri_base;
-    r.inner_base = bi.inner_base;
-    for (int k = 0; k < 3; k++) {
-        r.root_lo[k] = bi.n_tris ? roots[6 * bi.root_base + k] : (T)0;
-        r.root_hi[k] = bi.n_tris ? roots[6 * bi.root_base + 3 + k] : (T)0;
-    }
+    make_objrec(slots[s], objects[slots[s].inscene_objid], blas, roots, n_vaos, r);
     out[s] = r;
 }
 template <typename T>

@@ -158,14 +158,20 @@ class Renderer:
         return out
 
     # ---- scene-manager side: the RDScene of this frame ------------------------------------------------
-    def set_scene(self, sc=None):
+    def prepare_scene(self, sc=None):
+        """The C arrays of an RDScene, built once: a caller that hands over the same scene every frame (bench.py) does
+        not pay the Python loops again."""
         sc = sc or self.scene
         objs, aabbs, lights = sc.c_objects(), sc.c_aabbs(), sc.c_lights()
         cam = sc.c_camera(self.W, self.H)
         w2c = np.ascontiguousarray(sc.transform_W2C(self.W, self.H), dtype=np.float32)
         sky = sc.c_skybox(getattr(self, "tex_handles", None))
-        self._check(self.L.lprt_set_scene(self.h, C.byref(objs), C.byref(aabbs), len(sc.objects), C.byref(lights),
-                                          len(sc.lights), C.byref(cam), _ptr(w2c), C.byref(sky) if sky else None), "lprt_set_scene")
+        return (objs, aabbs, len(sc.objects), lights, len(sc.lights), cam, w2c, sky)
+
+    def set_scene(self, sc=None, prepared=None):
+        objs, aabbs, n, lights, nl, cam, w2c, sky = prepared if prepared is not None else self.prepare_scene(sc)
+        self._check(self.L.lprt_set_scene(self.h, C.byref(objs), C.byref(aabbs), n, C.byref(lights), nl, C.byref(cam), _ptr(w2c),
+                                          C.byref(sky) if sky else None), "lprt_set_scene")
 
     def load_scene(self, sc):
         self.set_rdresource(sc)
