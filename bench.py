@@ -250,7 +250,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spp", type=int, default=4)
-    ap.add_argument("--scene", default="cornell")
+    ap.add_argument("--scene", default="cornell", help="generated scene name or a .gltf/.glb path")
     ap.add_argument("--no-fp16", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true")
@@ -274,7 +274,13 @@ def main():
         else:
             torch.distributed.init_process_group(args.backend)
 
-    sc = scenes.SCENES[args.scene]()
+    if args.scene in scenes.SCENES:
+        sc = scenes.SCENES[args.scene]()
+    elif os.path.exists(args.scene):  # a .gltf / .glb file, e.g. the real Sponza when the operator supplies it
+        from lprt_amd import gltf
+        sc = gltf.load_gltf(args.scene)
+    else:
+        raise SystemExit(f"unknown scene {args.scene!r}: one of {sorted(scenes.SCENES)} or a path to a .gltf/.glb file")
     W, H, spp = args.width, args.height, args.spp
     res32 = measure(abi.F32, sc, W, H, spp, args.steps, args.warmup, rank, world, local, not args.no_stage_timing, args.backend)
     res16 = None if args.no_fp16 else measure(abi.F16, sc, W, H, spp, args.steps, args.warmup, rank, world, local,
