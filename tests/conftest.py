@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the suites need the product library (symbol / layout checks on CPU, everything on GPU): build it when a fresh
+    # checkout has not been through __graft_entry__.build() yet (hipcc cross-compiles without a GPU)
+    lib = os.path.join(ROOT, "low-precision-raytracer_amd", "csrc", "liblprt_hip.so")
+    if not os.path.exists(lib):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.dirname(lib), "-j8"], check=True, capture_output=True)
 
 
 def _has_gpu():
