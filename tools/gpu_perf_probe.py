@@ -29,7 +29,7 @@ def main():
             r = lprt_amd.Renderer(1920, 1080, prec); r.load_scene(sc)
             fs = abi.default_settings(spp=4)
             for rep in range(2):
-                for mode in ("0", "1", "2"):
+                for mode in ("0", "1"):
                     os.environ["LPRT_TLAS_MODE"] = mode
                     ms, st = timed(r, sc, fs, frames=8)
                     print(f"cornell prec={prec} tlas_mode={mode} rep={rep}: {ms:.3f} ms  primary={st['primary']} di1={st['trace_di1']} gi={st['trace_gi']} di2={st['trace_di2']}", flush=True)
