@@ -539,6 +539,7 @@ template <typename T> struct Impl : CtxBase {
             if (v == 0u || (v == 1u && tlas.n_objects <= 32u))
                 sc.tlas_mode = v;
         }
+        sc.axis_reject = std::getenv("LPRT_NO_AXIS_REJECT") ? 0u : 1u; // A/B switch (results must not depend on it)
         sc.objects = d_objects.template as<ObjConst<T>>();
         sc.blas = geo.d_blas.template as<BlasInfo>();
         sc.blas_roots = geo.d_roots.template as<T>();

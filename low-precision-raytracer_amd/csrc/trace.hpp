@@ -28,11 +28,13 @@ template <typename T> LPRT_DEV RayT<T> transform_ray(const RayT<T> &r, const M4<
 template <typename T> struct RaySlab {
     V3<T> o;
     float ix, iy, iz;
-    uint32_t par; // bit k: the ray does not move along axis k (1/d is not finite)
+    uint32_t par;    // bit k: the ray does not move along axis k (1/d is not finite)
+    uint32_t reject; // 0: the reference's plain test only (A/B switch, SceneDev::axis_reject)
 };
-template <typename T> LPRT_DEV RaySlab<T> make_slab(const RayT<T> &r) {
-    RaySlab<T> s{r.o, 1.0f / (float)r.d.x, 1.0f / (float)r.d.y, 1.0f / (float)r.d.z, 0u};
-    s.par = (__builtin_isfinite(s.ix) ? 0u : 1u) | (__builtin_isfinite(s.iy) ? 0u : 2u) | (__builtin_isfinite(s.iz) ? 0u : 4u);
+template <typename T> LPRT_DEV RaySlab<T> make_slab(const RayT<T> &r, uint32_t reject) {
+    RaySlab<T> s{r.o, 1.0f / (float)r.d.x, 1.0f / (float)r.d.y, 1.0f / (float)r.d.z, 0u, reject};
+    if (reject)
+        s.par = (__builtin_isfinite(s.ix) ? 0u : 1u) | (__builtin_isfinite(s.iy) ? 0u : 2u) | (__builtin_isfinite(s.iz) ? 0u : 4u);
     return s;
 }
 // A ray that does not move along an axis can only hit what its origin lies inside of on that axis.  The reference's slab
@@ -97,12 +99,10 @@ template <typename T, bool SCENE, bool PAR = false> LPRT_DEV bool slab_test(cons
     tmx = t2min;
     if (!(ok0 | ok1 | ok2))
         return false;
-#ifndef LPRT_NO_AXIS_REJECT // A/B knob: the reference's plain test
     if (PAR && stationary_reject(lo, hi, rs)) // only in the instantiation that rays with a stationary axis take
         return false;
-    if (Num<T>::is_half && !(ok0 & ok1 & ok2) && overflowed_axes_miss(lo, hi, rs, ok0, ok1, ok2, (float)t1max, (float)t2min))
+    if (Num<T>::is_half && rs.reject && !(ok0 & ok1 & ok2) && overflowed_axes_miss(lo, hi, rs, ok0, ok1, ok2, (float)t1max, (float)t2min))
         return false;
-#endif
     if (SCENE) {
         T s = t2min + cvt<T>(0.02f);
         return t1max <= s && 0.0f <= (float)s;
@@ -327,7 +327,7 @@ LPRT_DEV Isect<T> cast_ray(const SceneDev<T> &sc, const RayT<T> &ray, uint32_t s
         cnt.rays++;
     if (sc.n_objects == 0)
         return is;
-    const RaySlab<T> rs = make_slab(ray);
+    const RaySlab<T> rs = make_slab(ray, sc.axis_reject);
     T tmn, tmx;
     if (sc.tlas_mode == 1u) {
         // Small scenes (the Cornell box has 8 instances): a tree over a handful of mutually overlapping boxes costs ~2n
@@ -355,7 +355,7 @@ LPRT_DEV Isect<T> cast_ray(const SceneDev<T> &sc, const RayT<T> &ray, uint32_t s
             // one code path for every instance: with an identity W2L the transform returns the ray unchanged
             // (x*1 + y*0 + z*0 is exact), and a wave mixing walls and boxes does not run the BLAS walk twice
             const RayT<T> lr = transform_ray(ray, ob.W2L);
-            const RaySlab<T> lrs = make_slab(lr);
+            const RaySlab<T> lrs = make_slab(lr, sc.axis_reject);
             if (lrs.par) // rare: the instantiation whose box tests also check the stationary axes
                 traverse_blas<T, ANY, COUNT, true>(sc, lr, lrs, ob, skip_vao, skip_off, is, min_distance, max_distance, cnt);
             else
@@ -399,7 +399,7 @@ LPRT_DEV Isect<T> cast_ray(const SceneDev<T> &sc, const RayT<T> &ray, uint32_t s
                 if (slab_test<T, true>(ob->lo, ob->hi, rs, tmn, tmx) && tmn < max_distance && tmx > min_distance) {
                     const ObjRec<T> obv = *ob;
                     const RayT<T> lr = transform_ray(ray, obv.W2L);
-                    const RaySlab<T> lrs = make_slab(lr);
+                    const RaySlab<T> lrs = make_slab(lr, sc.axis_reject);
                     if (lrs.par)
                         traverse_blas<T, ANY, COUNT, true>(sc, lr, lrs, obv, skip_vao, skip_off, is, min_distance, max_distance, cnt);
                     else

@@ -428,3 +428,25 @@ def test_degenerate_scenes_render_without_faults(cornell):
     ref.load_scene(scenes.small_test_scene())
     ref.render(abi.default_settings(spp=1))
     assert np.array_equal(r3.read("OUTPUT"), ref.read("OUTPUT"), equal_nan=True)
+
+
+@pytest.mark.parametrize("prec", [abi.F32, abi.F16])
+def test_axis_rejections_never_change_a_frame(sponza, prec, monkeypatch):
+    """trace.hpp's stationary / overflowed-axis rejections only drop boxes a ray cannot reach: with them switched off
+    (LPRT_NO_AXIS_REJECT: the reference's plain slab test, 2-5x slower in half precision at this scene's scale) the
+    frames are bit-identical, in both precisions, over two frames of the 262 k-triangle atrium."""
+    outs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("LPRT_NO_AXIS_REJECT", "1")
+        else:
+            monkeypatch.delenv("LPRT_NO_AXIS_REJECT", raising=False)
+        r = lprt_amd.Renderer(256, 144, prec)
+        r.load_scene(sponza)
+        for _ in range(2):
+            r.set_scene(sponza)
+            r.render(abi.default_settings(spp=2))
+        outs.append((r.read("OUTPUT"), r.read("G_OFFSET"), r.read("INTENSITY1")))
+        r.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b, equal_nan=True)
