@@ -307,6 +307,10 @@ template <typename T> struct Impl : CtxBase {
         };
         stage(LPRT_STAGE_PRIMARY, [&] { launch_fill_gbuffer<T>(stream, sc, fb, stage_counters(LPRT_STAGE_PRIMARY)); });
         const bool first = frame_index == 0;
+        // shadow rays walk deep BLAS trees two levels per step (trace.hpp); LPRT_WIDE_WALK=0|1 overrides for A/B runs
+        bool wide_walk = geo.max_depth >= 6;
+        if (const char *w = std::getenv("LPRT_WIDE_WALK"))
+            wide_walk = w[0] == '1';
         // every curand_init of this frame in one batch: seed A of sample 0 (TAA jitter, frames >= 1) + seed B of each
         // sample (shade #1 with GI).  shade #2 runs with NO_GI and draws nothing (cuda.hpp:1900-1999).
         std::vector<uint64_t> seeds;
@@ -336,13 +340,13 @@ template <typename T> struct Impl : CtxBase {
             }
             stage(LPRT_STAGE_SHADE1, [&] { launch_shade<T>(stream, sc, fb, !fs.gi_on, d_b, s); });
             stage(LPRT_STAGE_TRACE_DI1, [&] {
-                launch_trace_di<T>(stream, sc, fb, true, fs.gi_on != 0, fs.add_direct_out != 0, s, spp, stage_counters(LPRT_STAGE_TRACE_DI1));
+                launch_trace_di<T>(stream, sc, fb, true, fs.gi_on != 0, fs.add_direct_out != 0, s, spp, stage_counters(LPRT_STAGE_TRACE_DI1), wide_walk);
             });
             if (fs.gi_on) {
                 // trace_gi + shade #2 of the hit in one kernel; trace_di #2 + write_clean_color + spp mean in the next
                 stage(LPRT_STAGE_TRACE_GI, [&] { launch_trace_gi<T>(stream, sc, fb, stage_counters(LPRT_STAGE_TRACE_GI)); });
                 stage(LPRT_STAGE_TRACE_DI2, [&] {
-                    launch_trace_di<T>(stream, sc, fb, false, true, fs.add_direct_out != 0, s, spp, stage_counters(LPRT_STAGE_TRACE_DI2));
+                    launch_trace_di<T>(stream, sc, fb, false, true, fs.add_direct_out != 0, s, spp, stage_counters(LPRT_STAGE_TRACE_DI2), wide_walk);
                 });
             }
         }

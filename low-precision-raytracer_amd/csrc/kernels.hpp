@@ -32,7 +32,8 @@ template <typename T> void launch_temporal_map(hipStream_t st, const SceneDev<T>
 template <typename T> void launch_shade(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool no_gi, uint32_t rng_d, uint32_t sample); // round 0; round 1 runs inside k_trace_gi
 template <typename T>
 void launch_trace_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, bool gi_on, bool add_direct, uint32_t sample, uint32_t spp,
-                     Counters *c); // the last round of a sample also composes (write_clean_color + spp mean)
+                     Counters *c, bool wide); // the last round of a sample also composes (write_clean_color + spp mean);
+                                              // wide: deep BLAS trees, walked two levels per step
 template <typename T> void launch_trace_gi(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, Counters *c);
 
 // svgf.hip

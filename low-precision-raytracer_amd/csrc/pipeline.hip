@@ -490,7 +490,7 @@ struct ComposeArgs {
     int gi_on, add_direct_out;
     uint32_t sample, spp;
 };
-template <typename T, bool FIRST, bool COMPOSE, bool COUNT>
+template <typename T, bool FIRST, bool COMPOSE, bool COUNT, bool WIDE>
 __global__ void __launch_bounds__(256, LPRT_ANYHIT_WAVES) k_trace_di(SceneDev<T> sc, FrameDev<T> fb, ComposeArgs ca, Counters *counters) {
     const uint32_t p = tile_pixel(fb);
     const uint32_t npix = fb.win.npix();
@@ -510,7 +510,7 @@ __global__ void __launch_bounds__(256, LPRT_ANYHIT_WAVES) k_trace_di(SceneDev<T>
                     const V4<T> dm = fb.lc_dir_maxt[i * npix + p];
                     const V3<T> mm = xyz(fb.lc_multiplier[i * npix + p]);
                     RayT<T> ray{source, xyz(dm)};
-                    Isect<T> is = cast_ray<T, true, COUNT>(sc, ray, skip.x, skip.y, cvt<T>(ray_moveforward_t<T>()), dm.w, cnt);
+                    Isect<T> is = cast_ray<T, true, COUNT, WIDE>(sc, ray, skip.x, skip.y, cvt<T>(ray_moveforward_t<T>()), dm.w, cnt);
                     di = (is.hit ? zero : one) * mm;
                 }
                 fc = fc + di;
@@ -630,27 +630,36 @@ template <typename T> void launch_shade(hipStream_t st, const SceneDev<T> &sc, c
         hipLaunchKernelGGL((k_shade<T, true>), g, b, 0, st, sc, fb, rng_d, sample);
 }
 // first: round 0 (composes when GI is off: it is the only round), else round 1 (always composes)
-template <typename T>
-void launch_trace_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, bool gi_on, bool add_direct, uint32_t sample, uint32_t spp,
-                     Counters *c) {
+// wide: the BLAS set holds deep trees (GeometryStore::max_depth >= 6): the shadow rays walk them two levels per step
+template <typename T, bool WIDE>
+static void launch_trace_di_w(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, bool gi_on, bool add_direct, uint32_t sample,
+                              uint32_t spp, Counters *c) {
     dim3 g = tile_grid(fb), b(256);
     ComposeArgs ca{gi_on ? 1 : 0, add_direct ? 1 : 0, sample, spp};
     if (first && gi_on) {
         if (c)
-            hipLaunchKernelGGL((k_trace_di<T, true, false, true>), g, b, 0, st, sc, fb, ca, c);
+            hipLaunchKernelGGL((k_trace_di<T, true, false, true, WIDE>), g, b, 0, st, sc, fb, ca, c);
         else
-            hipLaunchKernelGGL((k_trace_di<T, true, false, false>), g, b, 0, st, sc, fb, ca, c);
+            hipLaunchKernelGGL((k_trace_di<T, true, false, false, WIDE>), g, b, 0, st, sc, fb, ca, c);
     } else if (first) {
         if (c)
-            hipLaunchKernelGGL((k_trace_di<T, true, true, true>), g, b, 0, st, sc, fb, ca, c);
+            hipLaunchKernelGGL((k_trace_di<T, true, true, true, WIDE>), g, b, 0, st, sc, fb, ca, c);
         else
-            hipLaunchKernelGGL((k_trace_di<T, true, true, false>), g, b, 0, st, sc, fb, ca, c);
+            hipLaunchKernelGGL((k_trace_di<T, true, true, false, WIDE>), g, b, 0, st, sc, fb, ca, c);
     } else {
         if (c)
-            hipLaunchKernelGGL((k_trace_di<T, false, true, true>), g, b, 0, st, sc, fb, ca, c);
+            hipLaunchKernelGGL((k_trace_di<T, false, true, true, WIDE>), g, b, 0, st, sc, fb, ca, c);
         else
-            hipLaunchKernelGGL((k_trace_di<T, false, true, false>), g, b, 0, st, sc, fb, ca, c);
+            hipLaunchKernelGGL((k_trace_di<T, false, true, false, WIDE>), g, b, 0, st, sc, fb, ca, c);
     }
+}
+template <typename T>
+void launch_trace_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, bool gi_on, bool add_direct, uint32_t sample, uint32_t spp,
+                     Counters *c, bool wide) {
+    if (wide)
+        launch_trace_di_w<T, true>(st, sc, fb, first, gi_on, add_direct, sample, spp, c);
+    else
+        launch_trace_di_w<T, false>(st, sc, fb, first, gi_on, add_direct, sample, spp, c);
 }
 template <typename T> void launch_trace_gi(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, Counters *c) {
     if (c)
@@ -663,7 +672,7 @@ template <typename T> void launch_trace_gi(hipStream_t st, const SceneDev<T> &sc
     template void launch_fill_gbuffer<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, Counters *);          \
     template void launch_temporal_map<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, uint32_t);      \
     template void launch_shade<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, uint32_t, uint32_t);   \
-    template void launch_trace_di<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, bool, bool, uint32_t, uint32_t, Counters *); \
+    template void launch_trace_di<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, bool, bool, uint32_t, uint32_t, Counters *, bool); \
     template void launch_trace_gi<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, Counters *);
 INST(float)
 INST(h16)

@@ -233,7 +233,7 @@ LPRT_DEV void leaf_range_dev(uint32_t k, uint32_t D, uint32_t n, uint32_t &l, ui
 }
 
 // ---- T4: BLAS traversal (replaces search_intersection_in_object, cuda.hpp:415-504) -----------------
-template <typename T, bool ANY, bool COUNT, bool PAR>
+template <typename T, bool ANY, bool COUNT, bool PAR, bool WIDE>
 LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, const RaySlab<T> &rs, const ObjRec<T> &ob, uint32_t skip_vao,
                             uint32_t skip_off, Isect<T> &is, T min_distance, T max_distance, Cnt<COUNT> &cnt) {
     if (COUNT)
@@ -259,6 +259,93 @@ LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, const Ray
                 return;
         }
         return;
+    }
+    // Two levels per step: the records of both children of node i are adjacent (heap order), and together they hold the four
+    // GRANDCHILD boxes.  A grandchild box lies inside its parent's box and the slab test is monotone in the bounds, so a ray
+    // that passes a grandchild box passes the child box too: the child boxes need not be tested.  One dependent fetch and
+    // four box tests per two levels instead of two fetches and four to six tests; the deferred siblings of a step are four
+    // bits of a 64-bit mask (node 4i + j), popped deepest first.
+    if (WIDE) {
+        uint32_t i = 1, c = 0;
+        unsigned long long pend = 0;
+        for (;;) {
+            bool dead = false;
+            while (c < D) {
+                uint32_t h = 0, first = 0;
+                if (c + 2 <= D) {
+                    const InnerNode<T> ra = inner[2 * i - 1], rb = inner[2 * i];
+                    if (COUNT)
+                        cnt.blas_nodes += 4;
+                    T n[4], x;
+                    bool hh;
+                    hh = slab_test<T, false, PAR>(ra.lo0, ra.hi0, rs, n[0], x) && n[0] < is.t && n[0] < max_distance && x > min_distance;
+                    h |= hh ? 1u : 0u;
+                    hh = slab_test<T, false, PAR>(ra.lo1, ra.hi1, rs, n[1], x) && n[1] < is.t && n[1] < max_distance && x > min_distance;
+                    h |= hh ? 2u : 0u;
+                    hh = slab_test<T, false, PAR>(rb.lo0, rb.hi0, rs, n[2], x) && n[2] < is.t && n[2] < max_distance && x > min_distance;
+                    h |= hh ? 4u : 0u;
+                    hh = slab_test<T, false, PAR>(rb.lo1, rb.hi1, rs, n[3], x) && n[3] < is.t && n[3] < max_distance && x > min_distance;
+                    h |= hh ? 8u : 0u;
+                    if (h) {
+                        T best = Num<T>::inf();
+                        bool have = false;
+#pragma unroll
+                        for (uint32_t k = 0; k < 4; k++)
+                            if (((h >> k) & 1u) && (!have || n[k] < best)) {
+                                best = n[k];
+                                first = k;
+                                have = true;
+                            }
+                        pend |= (unsigned long long)(h & ~(1u << first)) << (2 * c); // bits 4*(c/2) ..: c is even here
+                        i = 4 * i + first;
+                        c += 2;
+                        continue;
+                    }
+                } else { // one level left above the leaves
+                    const InnerNode<T> nd = inner[i - 1];
+                    if (COUNT)
+                        cnt.blas_nodes += 2;
+                    T n0, x0, n1, x1;
+                    const bool h0 = slab_test<T, false, PAR>(nd.lo0, nd.hi0, rs, n0, x0) && n0 < is.t && n0 < max_distance && x0 > min_distance;
+                    const bool h1 = slab_test<T, false, PAR>(nd.lo1, nd.hi1, rs, n1, x1) && n1 < is.t && n1 < max_distance && x1 > min_distance;
+                    if (h0 | h1) {
+                        first = (h0 && (!h1 || n0 <= n1)) ? 0u : 1u;
+                        if (h0 & h1)
+                            pend |= (unsigned long long)(1u << (first ^ 1u)) << (2 * c);
+                        i = 2 * i + first;
+                        c += 1;
+                        continue;
+                    }
+                }
+                dead = true; // nothing hit below this node
+                break;
+            }
+            if (!dead) {
+                uint32_t l, r;
+                leaf_range_dev(i - (1u << D), D, ob.n_tris, l, r);
+                for (uint32_t k = l; k < r; k++) {
+                    uint32_t rec = ob.tri_base + k;
+                    if (skip_here && sc.tris[rec].inobject_offset == skip_off) // cuda.hpp:446
+                        continue;
+                    tri_test<T, COUNT>(sc, rec, ray, ob.inscene_objid, is, min_distance, max_distance, cnt);
+                    if (ANY && is.hit)
+                        return;
+                }
+            }
+            if (!pend)
+                return;
+            const uint32_t bit = 63u - (uint32_t)__builtin_clzll(pend);
+            pend ^= 1ull << bit;
+            const uint32_t k2 = (bit >> 2) * 2, j = bit & 3u; // depth of the node the step started from, child slot
+            const uint32_t anc = i >> (c - k2);
+            if (k2 + 2 <= D) {
+                i = (anc << 2) | j;
+                c = k2 + 2;
+            } else {
+                i = (anc << 1) | j;
+                c = k2 + 1;
+            }
+        }
     }
     // "while-while": every lane first walks inner nodes until it stands on a leaf (or runs out of work), then the
     // whole wave tests triangles; the two code paths are not interleaved per iteration.
@@ -314,7 +401,7 @@ LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, const Ray
 }
 
 // ---- T5: TLAS traversal + cast_ray (cuda.hpp:517-631) ---------------------------------------------
-template <typename T, bool ANY, bool COUNT>
+template <typename T, bool ANY, bool COUNT, bool WIDE = false>
 LPRT_DEV Isect<T> cast_ray(const SceneDev<T> &sc, const RayT<T> &ray, uint32_t skip_vao, uint32_t skip_off, T min_distance,
                            T max_distance, Cnt<COUNT> &cnt) {
     Isect<T> is;
@@ -357,9 +444,9 @@ LPRT_DEV Isect<T> cast_ray(const SceneDev<T> &sc, const RayT<T> &ray, uint32_t s
             const RayT<T> lr = transform_ray(ray, ob.W2L);
             const RaySlab<T> lrs = make_slab(lr, sc.axis_reject);
             if (lrs.par) // rare: the instantiation whose box tests also check the stationary axes
-                traverse_blas<T, ANY, COUNT, true>(sc, lr, lrs, ob, skip_vao, skip_off, is, min_distance, max_distance, cnt);
+                traverse_blas<T, ANY, COUNT, true, WIDE>(sc, lr, lrs, ob, skip_vao, skip_off, is, min_distance, max_distance, cnt);
             else
-                traverse_blas<T, ANY, COUNT, false>(sc, lr, lrs, ob, skip_vao, skip_off, is, min_distance, max_distance, cnt);
+                traverse_blas<T, ANY, COUNT, false, WIDE>(sc, lr, lrs, ob, skip_vao, skip_off, is, min_distance, max_distance, cnt);
             if (ANY && is.hit)
                 return is;
         }
@@ -401,9 +488,9 @@ LPRT_DEV Isect<T> cast_ray(const SceneDev<T> &sc, const RayT<T> &ray, uint32_t s
                     const RayT<T> lr = transform_ray(ray, obv.W2L);
                     const RaySlab<T> lrs = make_slab(lr, sc.axis_reject);
                     if (lrs.par)
-                        traverse_blas<T, ANY, COUNT, true>(sc, lr, lrs, obv, skip_vao, skip_off, is, min_distance, max_distance, cnt);
+                        traverse_blas<T, ANY, COUNT, true, WIDE>(sc, lr, lrs, obv, skip_vao, skip_off, is, min_distance, max_distance, cnt);
                     else
-                        traverse_blas<T, ANY, COUNT, false>(sc, lr, lrs, obv, skip_vao, skip_off, is, min_distance, max_distance, cnt);
+                        traverse_blas<T, ANY, COUNT, false, WIDE>(sc, lr, lrs, obv, skip_vao, skip_off, is, min_distance, max_distance, cnt);
                     if (ANY && is.hit)
                         return is;
                 }
