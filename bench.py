@@ -69,7 +69,7 @@ def barrier_sync(world):
     torch.cuda.synchronize()
 
 
-def measure(prec, sc, W, H, spp, steps, warmup, rank, world, device, stage_timing=True, backend="nccl", rebuild_blas=False):
+def measure(prec, sc, W, H, spp, steps, warmup, rank, world, device, stage_timing=True, backend="nccl", rebuild_blas=False, reuse_direct=False):
     """Times `steps` frames; returns a dict (identical on every rank for the reduced fields)."""
     win_b, win_e = lp_dist.window_rows(H, world, rank)
     r = lprt_amd.Renderer(W, H, prec, device=device, row_begin=win_b, row_end=win_e)
@@ -88,6 +88,7 @@ def measure(prec, sc, W, H, spp, steps, warmup, rank, world, device, stage_timin
     r.enable_stage_timing(False)
     fs = abi.default_settings(spp=spp, gi_on=True, svgf=True)
     fs.rebuild_blas = int(rebuild_blas)
+    fs.reuse_direct_light = int(reuse_direct)
 
     last = {}
 
@@ -254,6 +255,8 @@ def main():
     ap.add_argument("--scene", default="cornell", help="generated scene name or a .gltf/.glb path")
     ap.add_argument("--no-fp16", action="store_true")
     ap.add_argument("--rebuild-blas", action="store_true", help="rebuild every BLAS inside each frame (BASELINE configs[3])")
+    ap.add_argument("--reuse-direct-light", action="store_true",
+                    help="cast the sample-invariant shadow rays of round 0 once per frame (same image, more frames/s, fewer executed rays)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true")
     ap.add_argument("--backend", default="nccl", help="nccl (RCCL over xGMI) | gloo (rehearsal: gathers through host memory)")
@@ -284,9 +287,9 @@ def main():
     else:
         raise SystemExit(f"unknown scene {args.scene!r}: one of {sorted(scenes.SCENES)} or a path to a .gltf/.glb file")
     W, H, spp = args.width, args.height, args.spp
-    res32 = measure(abi.F32, sc, W, H, spp, args.steps, args.warmup, rank, world, local, not args.no_stage_timing, args.backend, args.rebuild_blas)
+    res32 = measure(abi.F32, sc, W, H, spp, args.steps, args.warmup, rank, world, local, not args.no_stage_timing, args.backend, args.rebuild_blas, args.reuse_direct_light)
     res16 = None if args.no_fp16 else measure(abi.F16, sc, W, H, spp, args.steps, args.warmup, rank, world, local,
-                                               not args.no_stage_timing, args.backend, args.rebuild_blas)
+                                               not args.no_stage_timing, args.backend, args.rebuild_blas, args.reuse_direct_light)
     if rank == 0:
         win_rows = res32["window_rows"][1] - res32["window_rows"][0]
         out = {

@@ -50,7 +50,7 @@ class FrameSettings(C.Structure):  # Renderer::Settings + DemoSetting (+ spp, se
     _fields_ = [("spp", u32), ("gi_on", u32), ("svgf", u32), ("add_direct_out", u32), ("add_gi_colored", u32),
                 ("add_gi_white", u32), ("demodulate", u32), ("svgf_color_mix_weight", f32),
                 ("svgf_moments_mix_weight", f32), ("taa_mix_weight", f32), ("seeds", C.POINTER(C.c_uint64)),
-                ("rebuild_blas", u32), ("reserved", u32)]
+                ("rebuild_blas", u32), ("reuse_direct_light", u32)]
 
 
 class Ray(C.Structure):

@@ -338,8 +338,11 @@ template <typename T> struct Impl : CtxBase {
                 fb.rng_state = d_rng_planes.as<uint32_t>() + (size_t)next_plane * 5 * npix;
                 d_b = seed_d[next_plane++];
             }
-            stage(LPRT_STAGE_SHADE1, [&] { launch_shade<T>(stream, sc, fb, !fs.gi_on, d_b, s); });
-            stage(LPRT_STAGE_TRACE_DI1, [&] {
+            // opt-in: round 0's light commands and their visibility do not depend on the sample -> cast them for sample 0 only
+            const bool reuse = fs.reuse_direct_light && fs.gi_on && s > 0;
+            stage(LPRT_STAGE_SHADE1, [&] { launch_shade<T>(stream, sc, fb, !fs.gi_on, d_b, s, reuse); });
+            if (!reuse)
+                stage(LPRT_STAGE_TRACE_DI1, [&] {
                 launch_trace_di<T>(stream, sc, fb, true, fs.gi_on != 0, fs.add_direct_out != 0, s, spp, stage_counters(LPRT_STAGE_TRACE_DI1), wide_walk);
             });
             if (fs.gi_on) {

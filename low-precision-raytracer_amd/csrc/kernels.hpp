@@ -29,7 +29,8 @@ void launch_sample_texture(hipStream_t st, const Texture *textures, const float 
 // pipeline.hip
 template <typename T> void launch_fill_gbuffer(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, Counters *c);
 template <typename T> void launch_temporal_map(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, uint32_t rng_d);
-template <typename T> void launch_shade(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool no_gi, uint32_t rng_d, uint32_t sample); // round 0; round 1 runs inside k_trace_gi
+template <typename T>
+void launch_shade(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool no_gi, uint32_t rng_d, uint32_t sample, bool skip_direct); // round 0; round 1 runs inside k_trace_gi
 template <typename T>
 void launch_trace_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, bool gi_on, bool add_direct, uint32_t sample, uint32_t spp,
                      Counters *c, bool wide); // the last round of a sample also composes (write_clean_color + spp mean);

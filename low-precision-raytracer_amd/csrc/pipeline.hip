@@ -265,7 +265,8 @@ template <typename T> struct ShadeIn {
 };
 
 template <typename T, bool FIRST, bool NO_GI>
-LPRT_DEV void shade_and_store(const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t p, uint32_t rng_d, const ShadeIn<T> &in, bool first_sample) {
+LPRT_DEV void shade_and_store(const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t p, uint32_t rng_d, const ShadeIn<T> &in, bool first_sample,
+                              bool skip_direct = false) {
     const uint32_t npix = fb.win.npix();
     const uint32_t x = p % fb.win.W, y = fb.win.row_begin + p / fb.win.W;
     const T zero = (T)0, one = (T)1;
@@ -395,10 +396,11 @@ LPRT_DEV void shade_and_store(const SceneDev<T> &sc, const FrameDev<T> &fb, uint
             o_intensity = mk4(sky.x, sky.y, sky.z, zero);
         }
 
-        // direct light commands (cuda.hpp:2009-2055)
+        // direct light commands (cuda.hpp:2009-2055).  skip_direct (opt-in, samples >= 1 of round 0): the commands and the
+        // visibility they lead to depend on the G-buffer and the lights only, so sample 0's radiance plane is kept as is
         const T rough_l = tmax(material.roughness, cvt<T>(0.10f));
         for (uint32_t i = 0; i < LPRT_MAX_DIRECT_LIGHT; i++) {
-            if (i >= sc.n_lights)
+            if (i >= sc.n_lights || skip_direct)
                 break;
             const LightT<T> light = sc.lights[i];
             V3<T> light_dir, mm = zero3<T>();
@@ -438,8 +440,10 @@ LPRT_DEV void shade_and_store(const SceneDev<T> &sc, const FrameDev<T> &fb, uint
         V3<T> sky = sample_skybox(sc, dir);
         o_intensity = mk4(sky.x, sky.y, sky.z, zero);
     }
-    fb.lc_mask[p] = (uint8_t)mask;
-    intensity[p] = o_intensity;
+    if (!skip_direct) {
+        fb.lc_mask[p] = (uint8_t)mask;
+        intensity[p] = o_intensity;
+    }
     fb.skips[p] = o_skip;
     if (!FIRST) // the shadow rays of round 1 start at the GI hit
         fb.sc_position[p] = live ? mk4(position.x, position.y, position.z, zero) : zero4;
@@ -453,7 +457,7 @@ LPRT_DEV void shade_and_store(const SceneDev<T> &sc, const FrameDev<T> &fb, uint
 }
 
 template <typename T, bool NO_GI>
-__global__ void __launch_bounds__(256) k_shade(SceneDev<T> sc, FrameDev<T> fb, uint32_t rng_d, uint32_t sample) {
+__global__ void __launch_bounds__(256) k_shade(SceneDev<T> sc, FrameDev<T> fb, uint32_t rng_d, uint32_t sample, uint32_t skip_direct) {
     const uint32_t p = tile_pixel(fb);
     if (p >= fb.win.npix())
         return;
@@ -480,7 +484,7 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev<T> sc, FrameDev<T> fb, u
         in.material = sc.materials[oc->materialid];
         in.objectid = oc->objectid;
     }
-    shade_and_store<T, true, NO_GI>(sc, fb, p, rng_d, in, sample == 0u);
+    shade_and_store<T, true, NO_GI>(sc, fb, p, rng_d, in, sample == 0u, skip_direct != 0u);
 }
 
 // ---- TD + A (+ W): trace_di_light + accumulate_di_light (cuda.hpp:2058-2081, 2143-2159); the LAST round of a sample
@@ -622,14 +626,14 @@ template <typename T> void launch_fill_gbuffer(hipStream_t st, const SceneDev<T>
 template <typename T> void launch_temporal_map(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, uint32_t rng_d) {
     hipLaunchKernelGGL(k_temporal_map<T>, grid_for(fb.win.npix()), dim3(256), 0, st, sc, fb, first ? 1 : 0, rng_d);
 }
-template <typename T> void launch_shade(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool no_gi, uint32_t rng_d, uint32_t sample) {
+template <typename T>
+void launch_shade(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool no_gi, uint32_t rng_d, uint32_t sample, bool skip_direct) {
     dim3 g = tile_grid(fb), b(256);
     if (!no_gi)
-        hipLaunchKernelGGL((k_shade<T, false>), g, b, 0, st, sc, fb, rng_d, sample);
+        hipLaunchKernelGGL((k_shade<T, false>), g, b, 0, st, sc, fb, rng_d, sample, skip_direct ? 1u : 0u);
     else
-        hipLaunchKernelGGL((k_shade<T, true>), g, b, 0, st, sc, fb, rng_d, sample);
+        hipLaunchKernelGGL((k_shade<T, true>), g, b, 0, st, sc, fb, rng_d, sample, skip_direct ? 1u : 0u);
 }
-// first: round 0 (composes when GI is off: it is the only round), else round 1 (always composes)
 // wide: the BLAS set holds deep trees (GeometryStore::max_depth >= 6): the shadow rays walk them two levels per step
 template <typename T, bool WIDE>
 static void launch_trace_di_w(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, bool gi_on, bool add_direct, uint32_t sample,
@@ -671,7 +675,7 @@ template <typename T> void launch_trace_gi(hipStream_t st, const SceneDev<T> &sc
 #define INST(T)                                                                                                        \
     template void launch_fill_gbuffer<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, Counters *);          \
     template void launch_temporal_map<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, uint32_t);      \
-    template void launch_shade<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, uint32_t, uint32_t);   \
+    template void launch_shade<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, uint32_t, uint32_t, bool); \
     template void launch_trace_di<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, bool, bool, uint32_t, uint32_t, Counters *, bool); \
     template void launch_trace_gi<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, Counters *);
 INST(float)

@@ -450,3 +450,25 @@ def test_axis_rejections_never_change_a_frame(sponza, prec, monkeypatch):
         r.close()
     for a, b in zip(*outs):
         assert np.array_equal(a, b, equal_nan=True)
+
+
+@pytest.mark.parametrize("scene_name", ["cornell", "small_test"])
+def test_reusing_round0_shadow_rays_gives_the_same_frames(scene_name):
+    """lprt_frame_settings.reuse_direct_light: the shadow rays of round 0 do not depend on the sample, so casting them for
+    sample 0 only must not change a single bit of any frame (three frames at 3 spp), while fewer rays are cast."""
+    sc = scenes.SCENES[scene_name]()
+    outs, rays = [], []
+    for reuse in (0, 1):
+        r = lprt_amd.Renderer(160, 96, abi.F32)
+        r.load_scene(sc)
+        r.enable_counters(True)
+        for _ in range(3):
+            fs = abi.default_settings(spp=3)
+            fs.reuse_direct_light = reuse
+            r.set_scene(sc)
+            r.render(fs)
+        outs.append([r.read(n) for n in ("OUTPUT", "INTENSITY0", "INTENSITY1", "COLOR_INPROGRESS")])
+        rays.append(r.counters()["rays"])
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b, equal_nan=True)
+    assert rays[1] < rays[0]
