@@ -223,7 +223,7 @@ def roofline_of(res, prec, npix_window, spp):
 
 def cpu_baseline(sc, spp):
     """The CPU oracle (a port of the reference pipeline; the reference has no CPU path) on a bounded sample of the
-    same workload: whole 1080p frames until ~10 s of CPU work have been spent (at most 4 frames)."""
+    same workload: whole 1080p frames until ~12 s of CPU work have been spent (at most 16 frames)."""
     from oracle.binding import Oracle
     W, H = 1920, 1080
     cores = min(len(os.sched_getaffinity(0)), 32)  # the GPU box grants a CPU share; more threads than that only thrash
@@ -232,7 +232,7 @@ def cpu_baseline(sc, spp):
     fs = abi.default_settings(spp=spp, gi_on=True, svgf=True)
     o.reset_counters()
     frames, t0 = 0, time.perf_counter()
-    while frames < 4 and (frames == 0 or time.perf_counter() - t0 < 10.0):
+    while frames < 16 and (frames == 0 or time.perf_counter() - t0 < 12.0):
         o.set_scene(sc)
         o.render_frame(fs)
         frames += 1
