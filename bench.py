@@ -69,14 +69,14 @@ def barrier_sync(world):
     torch.cuda.synchronize()
 
 
-def measure(prec, sc, W, H, spp, steps, warmup, rank, world, device, stage_timing=True, backend="nccl", rebuild_blas=False, reuse_direct=False):
+def measure(prec, sc, W, H, spp, steps, warmup, rank, world, device, stage_timing=True, backend="nccl", rebuild_blas=False, reuse_direct=False,
+            trace_halo=False):
     """Times `steps` frames; returns a dict (identical on every rank for the reduced fields)."""
     win_b, win_e = lp_dist.window_rows(H, world, rank)
     r = lprt_amd.Renderer(W, H, prec, device=device, row_begin=win_b, row_end=win_e)
     r.set_stream(torch.cuda.current_stream().cuda_stream)
-    frame = lp_dist.ShardedFrame(W, H, rank, world, torch.device("cuda", device), backend=backend)
-    ptr, first_row, n_rows = frame.target()
-    r.set_output_target(ptr, first_row, n_rows)
+    frame = lp_dist.ShardedFrame(W, H, rank, world, torch.device("cuda", device), backend=backend, trace_halo=trace_halo)
+    frame.attach(r)  # output rows -> this rank's slot of the gathered image; N > 1: the spp loop runs on the owned rows only
     r.load_scene(sc)
     # BVH build rate, reported apart (SURVEY.md 8(d)): BLAS of every primitive, three timed rebuilds after the first
     r.enable_stage_timing(True)
@@ -96,9 +96,9 @@ def measure(prec, sc, W, H, spp, steps, warmup, rank, world, device, stage_timin
 
     def step():
         r.set_scene(prepared=prepared)   # per-frame RDScene hand-over + TLAS rebuild (rt/rtrt/cuda.hpp:662-710)
-        r.render(fs)
-        if world > 1:     # temporal history of the halo rows comes from the ranks that own them (dist.py)
-            last["hist_bytes"] = frame.exchange_history(r, stream_ordered=True)  # r enqueues on torch's current stream
+        # N > 1: the halo rows' sample means and temporal history come from the ranks that own them, one point-to-point
+        # batch per frame between the two render phases (dist.py); r enqueues on torch's current stream
+        last["hist_bytes"] = frame.render(r, fs, stream_ordered=True)
         last["image"] = frame.all_gather()
 
     # rays of one whole frame (full image, rank 0) and per-kernel work counters of THIS rank's launches: one
@@ -164,7 +164,8 @@ def measure(prec, sc, W, H, spp, steps, warmup, rank, world, device, stage_timin
     out_ok = bool(torch.isfinite(last["image"]).all().item()) and bool((last["image"][..., 3] == 1).all().item())
     res = dict(dt=dt, ms_per_step=1e3 * dt / steps, frames_per_s=steps / dt, frame_rays=frame_rays,
                mrays_per_s=frame_rays * steps / dt / 1e6, stage=stage, calib=calib, stage_counters=stage_counters,
-               finite=out_ok, window_rows=[win_b, win_e], build_blas_ms=build_ms)
+               finite=out_ok, window_rows=[win_b, win_e], build_blas_ms=build_ms,
+               sample_rows=(win_e - win_b) if frame.trace_halo else (frame.end - frame.begin))
     r.close()
     return res
 
@@ -185,7 +186,10 @@ def pmc_traffic(kernel, prec):
     return None, None
 
 
-def roofline_of(res, prec, npix_window, spp):
+SAMPLE_STAGES = ("rng", "shade1", "shade2", "compose", "trace_di1", "trace_gi", "trace_di2")  # run on the sample rows only
+
+
+def roofline_of(res, prec, width, spp):
     """Dominant kernel family (largest HIP-event time over the calibration frames) against the HBM roof; its launch
     duration is the live average over the timed region, where it is the only instrumented stage."""
     i = 0 if prec == abi.F32 else 1
@@ -199,6 +203,7 @@ def roofline_of(res, prec, npix_window, spp):
         return None
     name, ms, launches = best
     avg_s = ms / launches / 1e3
+    npix_window = width * (res["sample_rows"] if name in SAMPLE_STAGES else res["window_rows"][1] - res["window_rows"][0])
     if name in RAY_IO:
         per_frame = trace_bytes(res["stage_counters"][name], name, prec)
         launches_per_frame = 1 if name == "primary" else spp
@@ -257,6 +262,8 @@ def main():
     ap.add_argument("--rebuild-blas", action="store_true", help="rebuild every BLAS inside each frame (BASELINE configs[3])")
     ap.add_argument("--reuse-direct-light", action="store_true",
                     help="cast the sample-invariant shadow rays of round 0 once per frame (same image, more frames/s, fewer executed rays)")
+    ap.add_argument("--trace-halo", action="store_true",
+                    help="N > 1: every rank also traces its 68 halo rows instead of receiving their sample means from the neighbours")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true")
     ap.add_argument("--backend", default="nccl", help="nccl (RCCL over xGMI) | gloo (rehearsal: gathers through host memory)")
@@ -287,11 +294,11 @@ def main():
     else:
         raise SystemExit(f"unknown scene {args.scene!r}: one of {sorted(scenes.SCENES)} or a path to a .gltf/.glb file")
     W, H, spp = args.width, args.height, args.spp
-    res32 = measure(abi.F32, sc, W, H, spp, args.steps, args.warmup, rank, world, local, not args.no_stage_timing, args.backend, args.rebuild_blas, args.reuse_direct_light)
+    res32 = measure(abi.F32, sc, W, H, spp, args.steps, args.warmup, rank, world, local, not args.no_stage_timing, args.backend, args.rebuild_blas,
+                    args.reuse_direct_light, args.trace_halo)
     res16 = None if args.no_fp16 else measure(abi.F16, sc, W, H, spp, args.steps, args.warmup, rank, world, local,
-                                               not args.no_stage_timing, args.backend, args.rebuild_blas, args.reuse_direct_light)
+                                               not args.no_stage_timing, args.backend, args.rebuild_blas, args.reuse_direct_light, args.trace_halo)
     if rank == 0:
-        win_rows = res32["window_rows"][1] - res32["window_rows"][0]
         out = {
             "metric": "Mray/s at 1920x1080, 4 spp (frames/s alongside), fp32 headline + fp16, Cornell-box glTF-equivalent scene",
             "value": res32["mrays_per_s"], "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -299,7 +306,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{sc.name} {W}x{H} {spp}spp fp32 gi=on svgf=on traced-primary (BASELINE.json configs[1])",
                        "triangles": sc.n_tris, "objects": len(sc.objects), "rays_per_frame": res32["frame_rays"],
-                       "parallelism": f"row-strips x{world} + halo {lp_dist.HALO_ROWS} + all-gather" if world > 1 else "single GPU"},
+                       "parallelism": (f"row-strips x{world} + halo {lp_dist.HALO_ROWS} ({'traced locally' if args.trace_halo else 'samples from the owners'})"
+                                       " + all-gather") if world > 1 else "single GPU"},
             "frames_per_s": res32["frames_per_s"],
             "mrays_per_s_trace_kernels_only": (res32["frame_rays"] / 1e3 / sum(res32["calib"][k][0] for k in ("primary", "trace_di1", "trace_gi", "trace_di2")
                                                                                   if k in res32["calib"])) if res32["calib"] else None,
@@ -315,8 +323,8 @@ def main():
                            "workload": f"{sc.name} {W}x{H} {spp}spp fp16 (BASELINE.json configs[2])",
                            "speedup_vs_f32": res16["mrays_per_s"] / res32["mrays_per_s"],
                            "stage_ms_per_frame": {k: v[0] for k, v in res16["calib"].items()},
-                           "roofline": roofline_of(res16, abi.F16, W * win_rows, spp) if res16["stage"] else None}
-        out["roofline"] = roofline_of(res32, abi.F32, W * win_rows, spp) if res32["stage"] else None
+                           "roofline": roofline_of(res16, abi.F16, W, spp) if res16["stage"] else None}
+        out["roofline"] = roofline_of(res32, abi.F32, W, spp) if res32["stage"] else None
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, spp)
         else:

@@ -277,6 +277,22 @@ int lprt_set_scene(lprt_ctx *ctx, const lprt_object *objects, const lprt_aabb *a
  * + render_cuda (rt/gui/imgui_window.cu:121-283). Asynchronous on the context's stream. */
 int lprt_render_frame(lprt_ctx *ctx, const lprt_frame_settings *settings);
 
+/* The same frame in two calls, for sharded rendering: LPRT_PHASE_SAMPLE runs render_gbuffer over the window and the spp
+ * loop of render_cuda (RNG, shade, shadow/GI rays, write_clean_color; imgui_window.cu:169-238) over the sample rows;
+ * LPRT_PHASE_RESOLVE runs the temporal maps, svgf_denoise, add_denoised_color, TAA and the output write
+ * (imgui_window.cu:141-167, 240-283) over the window.  lprt_render_frame = both.  Between the two, a context whose sample
+ * rows are narrower than its window imports the sample means of its other rows (LPRT_HIST_SAMPLES) from the contexts
+ * that traced them. */
+#define LPRT_PHASE_SAMPLE 1
+#define LPRT_PHASE_RESOLVE 2
+int lprt_render_phase(lprt_ctx *ctx, const lprt_frame_settings *settings, int phase);
+
+/* Image rows [first_row, first_row + n_rows) of the window on which LPRT_PHASE_SAMPLE runs the per-sample stages;
+ * n_rows = 0 (the default): the whole window.  With the rows a rank owns here, the halo rows cost no rays: their sample
+ * means arrive from the neighbours (RNG streams are keyed by the global pixel index, so they are the values this
+ * context would have computed). */
+int lprt_set_sample_rows(lprt_ctx *ctx, uint32_t first_row, uint32_t n_rows);
+
 /* Drops temporal history (frame counter back to 0): the state right after Renderer construction. */
 int lprt_reset_history(lprt_ctx *ctx);
 
@@ -302,6 +318,8 @@ int lprt_set_output_target(lprt_ctx *ctx, void *dst_device, uint32_t first_row, 
  * context's stream. */
 #define LPRT_HIST_FILTER 1u /* SVGF colour + moment history of both lobes, frame counters: needed on the whole halo */
 #define LPRT_HIST_TAA 2u    /* TAA history: read only within +-1 row (+ motion) of the rows a context owns */
+#define LPRT_HIST_SAMPLES 4u /* not history: this frame's per-lobe sample means (the denoiser's input), exchanged between
+                              * LPRT_PHASE_SAMPLE and LPRT_PHASE_RESOLVE when halo rows are not traced locally */
 int lprt_history_row_bytes(lprt_ctx *ctx, uint32_t groups, size_t *bytes);
 int lprt_export_history_rows(lprt_ctx *ctx, uint32_t groups, uint32_t first_row, uint32_t n_rows, void *dst_device);
 int lprt_import_history_rows(lprt_ctx *ctx, uint32_t groups, uint32_t first_row, uint32_t n_rows, const void *src_device);

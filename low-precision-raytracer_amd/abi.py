@@ -72,6 +72,8 @@ class Counters(C.Structure):
 
 HIST_FILTER, HIST_TAA = 1, 2   # groups of temporal-history planes (include/lprt.h)
 HIST_ALL = HIST_FILTER | HIST_TAA
+HIST_SAMPLES = 4               # this frame's per-lobe sample means, exchanged between the two render phases
+PHASE_SAMPLE, PHASE_RESOLVE = 1, 2
 BUF = dict(COLOR_INPROGRESS=0, MUL_GI_COLORED=1, MUL_GI_WHITE=2, INTENSITY0=3, INTENSITY1=4, ALBEDO=5, OUTPUT=6,
            G_POSITION=7, G_NORMAL_DEPTH=8, G_TANGENT=9, G_UV0UV1=10, G_COLOR=11, G_OBJID=12, G_OFFSET=13,
            RAW_GI_COLORED=14, RAW_GI_WHITE=15, RAW_COLOR=16, GI_DIRECTION=17)

@@ -67,14 +67,32 @@ struct CtxBase {
     virtual void blas_info(uint32_t, uint32_t *, uint32_t *, uint32_t *) = 0;
     virtual void read_blas_order(uint32_t, uint32_t *, uint32_t) = 0;
     virtual void read_blas_boxes(uint32_t, float *, uint32_t) = 0;
-    virtual void render_frame(const lprt_frame_settings &) = 0;
+    virtual void render_phase(const lprt_frame_settings &, int phase) = 0;
+    void render_frame(const lprt_frame_settings &fs) {
+        render_phase(fs, LPRT_PHASE_SAMPLE);
+        render_phase(fs, LPRT_PHASE_RESOLVE);
+    }
+    // rows of the window the per-sample stages (RNG, shade, trace) run on; the rest of the window gets its sample means
+    // from the contexts that own those rows (LPRT_HIST_SAMPLES) between the two phases
+    uint32_t sample_first = 0, sample_rows = 0; // 0 rows: the whole window
+    int next_phase = LPRT_PHASE_SAMPLE;
+    void set_sample_rows(uint32_t first_row, uint32_t n_rows) {
+        if (n_rows == 0) {
+            sample_first = sample_rows = 0;
+            return;
+        }
+        if (first_row < win.row_begin || first_row + n_rows > win.row_end)
+            throw std::string("sample rows must lie inside this context's row window");
+        sample_first = first_row;
+        sample_rows = n_rows;
+    }
     virtual void reset_history() = 0;
     virtual void read_buffer(lprt_buffer_id, float *, size_t) = 0;
     virtual void output_ptr(void **, size_t *) = 0;
     struct HistPlane {
         void *ptr;
         size_t bytes_per_pixel;
-        uint32_t group; // LPRT_HIST_FILTER | LPRT_HIST_TAA
+        uint32_t group; // LPRT_HIST_FILTER | LPRT_HIST_TAA | LPRT_HIST_SAMPLES
     };
     virtual std::vector<HistPlane> history_planes() = 0;
     size_t history_row_bytes(uint32_t groups) {
@@ -276,19 +294,32 @@ template <typename T> struct Impl : CtxBase {
     }
     void reset_history() override {
         frame_index = 0;
+        next_phase = LPRT_PHASE_SAMPLE;
         if (arena.ptr)
             LPRT_HIP(hipMemsetAsync(arena.ptr, 0, arena_bytes, stream));
     }
-    void render_frame(const lprt_frame_settings &fs) override {
-        require_ready();
-        ensure_frame_buffers();
-        ensure_last_L2W();
-        const uint32_t spp = fs.spp ? fs.spp : 1;
-        if (fs.rebuild_blas) {
-            stage(LPRT_STAGE_BUILD_BLAS, [&] { geo.build_blas(stream); });
-            objrecs_dirty = true;
-            ensure_objrecs();
+    // the per-pixel planes of fb restricted to image rows [first, first + n): same storage, shifted pointers.  The
+    // slot-major light-command planes and the RNG planes are scratch of the per-sample stages, indexed with the view's own
+    // pixel count, and stay where they are.
+    FrameDev<T> rows_view(uint32_t first, uint32_t n) const {
+        FrameDev<T> v = fb;
+        const size_t skip = (size_t)(first - win.row_begin) * win.W;
+        auto sh = [skip](auto *&ptr) { ptr += skip; };
+        sh(v.g_position), sh(v.g_normal_depth), sh(v.g_tangent), sh(v.g_uv), sh(v.g_color), sh(v.g_objid), sh(v.g_offset);
+        sh(v.gi_multiplier), sh(v.intensity0), sh(v.intensity1), sh(v.skips), sh(v.gi_direction), sh(v.gi_valid), sh(v.lc_mask);
+        sh(v.sc_position), sh(v.albedo), sh(v.color_inprogress), sh(v.taa_history);
+        sh(v.acc_color), sh(v.acc_gi_colored), sh(v.acc_gi_white), sh(v.raw_color), sh(v.raw_gi_colored), sh(v.raw_gi_white);
+        for (int l = 0; l < 2; l++) {
+            SvgfLobe<T> &lb = v.lobe[l];
+            sh(lb.cv_a), sh(lb.cv_b), sh(lb.cv_c), sh(lb.illum), sh(lb.var_a), sh(lb.var_b), sh(lb.var_c);
+            sh(lb.miu1_hist), sh(lb.miu2_hist), sh(lb.miu1_cur), sh(lb.miu2_cur);
         }
+        sh(v.depth_gradient), sh(v.svgf_map), sh(v.taa_map), sh(v.valid_frame_count), sh(v.prev_frame_count), sh(v.last_frame_id), sh(v.output);
+        v.win.row_begin = first;
+        v.win.row_end = first + n;
+        return v;
+    }
+    SceneDev<T> frame_scene() {
         SceneDev<T> sc = scene_dev();
         // camera + reprojection matrices in DataT (RDCamera<DataT>, transform_W2C)
         for (int k = 0; k < 16; k++)
@@ -299,7 +330,34 @@ template <typename T> struct Impl : CtxBase {
         sc.sky_dx = (T)skybox.delta_x;
         sc.sky_dy = (T)skybox.delta_y;
         sc.sky_exposure = (T)skybox.exposure;
+        return sc;
+    }
+    uint32_t jitter_d = 0; // d word of this frame's seed A, drawn in the sample phase, used by the temporal maps
+    void render_phase(const lprt_frame_settings &fs, int phase) override {
+        if (phase != next_phase)
+            throw std::string("render phases out of order: LPRT_PHASE_SAMPLE, then LPRT_PHASE_RESOLVE");
+        if (phase == LPRT_PHASE_SAMPLE)
+            sample_phase(fs);
+        else
+            resolve_phase(fs);
+        next_phase = phase == LPRT_PHASE_SAMPLE ? LPRT_PHASE_RESOLVE : LPRT_PHASE_SAMPLE;
+    }
+    // primary rays over the window; RNG, shade #1/#2, shadow and GI rays, spp mean over the sample rows
+    void sample_phase(const lprt_frame_settings &fs) {
+        require_ready();
+        ensure_frame_buffers();
+        ensure_last_L2W();
+        const uint32_t spp = fs.spp ? fs.spp : 1;
+        if (fs.rebuild_blas) {
+            stage(LPRT_STAGE_BUILD_BLAS, [&] { geo.build_blas(stream); });
+            objrecs_dirty = true;
+            ensure_objrecs();
+        }
+        SceneDev<T> sc = frame_scene();
+        const bool whole = sample_rows == 0 || (sample_first == win.row_begin && sample_rows == win.rows());
+        FrameDev<T> sv = whole ? fb : rows_view(sample_first, sample_rows);
         const uint32_t total_px = win.W * win.H, first_px = win.row_begin * win.W, npix = win.npix();
+        const uint32_t s_first_px = sv.win.row_begin * win.W, s_npix = sv.win.npix();
         auto seed_of = [&](uint32_t s, int which) -> uint64_t {
             if (fs.seeds)
                 return fs.seeds[3 * s + (uint32_t)which];
@@ -311,48 +369,65 @@ template <typename T> struct Impl : CtxBase {
         bool wide_walk = geo.max_depth >= 6;
         if (const char *w = std::getenv("LPRT_WIDE_WALK"))
             wide_walk = w[0] == '1';
-        // every curand_init of this frame in one batch: seed A of sample 0 (TAA jitter, frames >= 1) + seed B of each
-        // sample (shade #1 with GI).  shade #2 runs with NO_GI and draws nothing (cuda.hpp:1900-1999).
-        std::vector<uint64_t> seeds;
+        // every curand_init of this frame: seed A of sample 0 (TAA jitter, frames >= 1) over the window + seed B of each
+        // sample (shade #1 with GI) over the sample rows -- one batch when the two row ranges coincide.  shade #2 runs with
+        // NO_GI and draws nothing (cuda.hpp:1900-1999).
+        std::vector<uint64_t> seeds_a, seeds_b;
         if (!first)
-            seeds.push_back(seed_of(0, 0));
+            seeds_a.push_back(seed_of(0, 0));
         if (fs.gi_on)
             for (uint32_t s = 0; s < spp; s++)
-                seeds.push_back(seed_of(s, 1));
-        std::vector<uint32_t> seed_d(seeds.size() + 1, 0u);
-        if (!seeds.empty()) {
-            d_rng_planes.reserve(sizeof(uint32_t) * 5 * (size_t)npix * seeds.size());
+                seeds_b.push_back(seed_of(s, 1));
+        std::vector<uint32_t> seed_d(seeds_a.size() + seeds_b.size() + 1, 0u);
+        const size_t b_planes_at = 5 * (size_t)npix * seeds_a.size();
+        if (!seeds_a.empty() || !seeds_b.empty()) {
+            d_rng_planes.reserve(sizeof(uint32_t) * (b_planes_at + 5 * (size_t)s_npix * seeds_b.size()));
             stage(LPRT_STAGE_RNG, [&] {
-                rng.generate(stream, seeds.data(), (uint32_t)seeds.size(), total_px, first_px, npix, d_rng_planes.as<uint32_t>(), seed_d.data());
+                uint32_t *planes = d_rng_planes.as<uint32_t>();
+                if (whole) {
+                    std::vector<uint64_t> all(seeds_a);
+                    all.insert(all.end(), seeds_b.begin(), seeds_b.end());
+                    rng.generate(stream, all.data(), (uint32_t)all.size(), total_px, first_px, npix, planes, seed_d.data());
+                } else {
+                    if (!seeds_a.empty())
+                        rng.generate(stream, seeds_a.data(), (uint32_t)seeds_a.size(), total_px, first_px, npix, planes, seed_d.data());
+                    if (!seeds_b.empty())
+                        rng.generate(stream, seeds_b.data(), (uint32_t)seeds_b.size(), total_px, s_first_px, s_npix, planes + b_planes_at,
+                                     seed_d.data() + seeds_a.size());
+                }
             });
         }
-        uint32_t next_plane = 0;
-        fb.rng_state = d_rng_planes.as<uint32_t>();
-        uint32_t d_a = first ? 0u : seed_d[next_plane];
-        stage(LPRT_STAGE_TEMPORAL_MAP, [&] { launch_temporal_map<T>(stream, sc, fb, first, d_a); });
-        if (!first)
-            next_plane++;
+        jitter_d = first ? 0u : seed_d[0];
         for (uint32_t s = 0; s < spp; s++) {
             uint32_t d_b = 0;
             if (fs.gi_on) {
-                fb.rng_state = d_rng_planes.as<uint32_t>() + (size_t)next_plane * 5 * npix;
-                d_b = seed_d[next_plane++];
+                sv.rng_state = d_rng_planes.as<uint32_t>() + b_planes_at + (size_t)s * 5 * s_npix;
+                d_b = seed_d[seeds_a.size() + s];
             }
             // opt-in: round 0's light commands and their visibility do not depend on the sample -> cast them for sample 0 only
             const bool reuse = fs.reuse_direct_light && fs.gi_on && s > 0;
-            stage(LPRT_STAGE_SHADE1, [&] { launch_shade<T>(stream, sc, fb, !fs.gi_on, d_b, s, reuse); });
+            stage(LPRT_STAGE_SHADE1, [&] { launch_shade<T>(stream, sc, sv, !fs.gi_on, d_b, s, reuse); });
             if (!reuse)
                 stage(LPRT_STAGE_TRACE_DI1, [&] {
-                launch_trace_di<T>(stream, sc, fb, true, fs.gi_on != 0, fs.add_direct_out != 0, s, spp, stage_counters(LPRT_STAGE_TRACE_DI1), wide_walk);
-            });
+                    launch_trace_di<T>(stream, sc, sv, true, fs.gi_on != 0, fs.add_direct_out != 0, s, spp, stage_counters(LPRT_STAGE_TRACE_DI1),
+                                       wide_walk);
+                });
             if (fs.gi_on) {
                 // trace_gi + shade #2 of the hit in one kernel; trace_di #2 + write_clean_color + spp mean in the next
-                stage(LPRT_STAGE_TRACE_GI, [&] { launch_trace_gi<T>(stream, sc, fb, stage_counters(LPRT_STAGE_TRACE_GI)); });
+                stage(LPRT_STAGE_TRACE_GI, [&] { launch_trace_gi<T>(stream, sc, sv, stage_counters(LPRT_STAGE_TRACE_GI)); });
                 stage(LPRT_STAGE_TRACE_DI2, [&] {
-                    launch_trace_di<T>(stream, sc, fb, false, true, fs.add_direct_out != 0, s, spp, stage_counters(LPRT_STAGE_TRACE_DI2), wide_walk);
+                    launch_trace_di<T>(stream, sc, sv, false, true, fs.add_direct_out != 0, s, spp, stage_counters(LPRT_STAGE_TRACE_DI2), wide_walk);
                 });
             }
         }
+        LPRT_HIP(hipGetLastError());
+    }
+    // temporal maps, SVGF, composition with the denoised lobes, TAA, output over the window
+    void resolve_phase(const lprt_frame_settings &fs) {
+        SceneDev<T> sc = frame_scene();
+        const bool first = frame_index == 0;
+        fb.rng_state = d_rng_planes.as<uint32_t>(); // seed A's planes (frames >= 1)
+        stage(LPRT_STAGE_TEMPORAL_MAP, [&] { launch_temporal_map<T>(stream, sc, fb, first, jitter_d); });
         const V4<T> *res0 = fb.lobe[0].cv_a, *res1 = fb.lobe[1].cv_a;
         svgf_ran = fs.svgf != 0;
         if (fs.svgf) {
@@ -441,6 +516,8 @@ template <typename T> struct Impl : CtxBase {
         }
         v.push_back({fb.prev_frame_count, 1, LPRT_HIST_FILTER});
         v.push_back({fb.taa_history, sizeof(V4<T>), LPRT_HIST_TAA});
+        for (int l = 0; l < 2; l++) // this frame's sample means (write_clean_color), the denoiser's input
+            v.push_back({fb.lobe[l].cv_a, sizeof(V4<T>), LPRT_HIST_SAMPLES});
         return v;
     }
     void output_ptr(void **ptr, size_t *bytes) override {
@@ -968,6 +1045,20 @@ int lprt_render_frame(lprt_ctx *ctx, const lprt_frame_settings *fs) {
             throw std::string("spp too large");
         c.render_frame(*fs);
     });
+}
+int lprt_render_phase(lprt_ctx *ctx, const lprt_frame_settings *fs, int phase) {
+    return guarded(ctx, [&](CtxBase &c) {
+        if (!fs)
+            throw std::string("null settings");
+        if (fs->spp > 4096)
+            throw std::string("spp too large");
+        if (phase != LPRT_PHASE_SAMPLE && phase != LPRT_PHASE_RESOLVE)
+            throw std::string("unknown render phase");
+        c.render_phase(*fs, phase);
+    });
+}
+int lprt_set_sample_rows(lprt_ctx *ctx, uint32_t first_row, uint32_t n_rows) {
+    return guarded(ctx, [&](CtxBase &c) { c.set_sample_rows(first_row, n_rows); });
 }
 int lprt_reset_history(lprt_ctx *ctx) {
     return guarded(ctx, [&](CtxBase &c) { c.reset_history(); });

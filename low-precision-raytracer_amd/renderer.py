@@ -37,6 +37,8 @@ SYMBOLS = [
     ("lprt_build_blas", C.c_int, [_P]),
     ("lprt_set_scene", C.c_int, [_P, _P, _P, C.c_uint32, _P, C.c_uint32, _P, _P, _P]),
     ("lprt_render_frame", C.c_int, [_P, _P]),
+    ("lprt_render_phase", C.c_int, [_P, _P, C.c_int]),
+    ("lprt_set_sample_rows", C.c_int, [_P, C.c_uint32, C.c_uint32]),
     ("lprt_reset_history", C.c_int, [_P]),
     ("lprt_read_buffer", C.c_int, [_P, C.c_int, _P, C.c_size_t]),
     ("lprt_output_device_ptr", C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_size_t)]),
@@ -184,6 +186,15 @@ class Renderer:
         self._check(self.L.lprt_render_frame(self.h, C.byref(settings)), "lprt_render_frame")
 
     render_frame = render
+
+    def render_phase(self, settings, phase):
+        """One half of a frame (abi.PHASE_SAMPLE, then abi.PHASE_RESOLVE); sharded rendering exchanges rows in between."""
+        self._settings_keepalive = settings
+        self._check(self.L.lprt_render_phase(self.h, C.byref(settings), int(phase)), "lprt_render_phase")
+
+    def set_sample_rows(self, first_row=0, n_rows=0):
+        """Image rows the per-sample stages run on (n_rows = 0: the whole window)."""
+        self._check(self.L.lprt_set_sample_rows(self.h, int(first_row), int(n_rows)), "lprt_set_sample_rows")
 
     def reset_history(self):
         self._check(self.L.lprt_reset_history(self.h), "lprt_reset_history")

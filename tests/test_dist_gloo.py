@@ -83,6 +83,19 @@ class _FakeRenderer:
     def history_row_bytes(self, groups=3):
         return self.ROW_BYTES
 
+    # the two-phase frame of trace_halo=False: the resolve phase must find every row of the window filled by its owner
+    def set_output_target(self, *a):
+        pass
+
+    def set_sample_rows(self, first, n):
+        self.sample_rows = (first, n)
+
+    def render_phase(self, k, phase):
+        if phase == 1:
+            self.render(k)
+        else:
+            self.resolved_ok = all(bool((self.rows[row] == (row * 7 + k) % 251).all()) for row in range(self.f.win_begin, self.f.win_end))
+
     def synchronize(self):
         pass
 
@@ -116,11 +129,27 @@ def _hist_worker(rank, world, port, H, halo, q):
     tdist.destroy_process_group()
 
 
-def _run_hist(H, world, halo):
+def _lean_worker(rank, world, port, H, halo, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+    frame = dist.ShardedFrame(4, H, rank, world, torch.device("cpu"), backend="gloo", halo=halo, trace_halo=False)
+    r = _FakeRenderer(frame)
+    frame.attach(r)
+    ok = r.sample_rows == (frame.begin, frame.end - frame.begin)
+    for k in range(3):
+        moved = frame.render(r, k)  # sample phase -> exchange (history + samples in one batch) -> resolve phase
+        ok = ok and r.resolved_ok and moved > 0
+    q.put((rank, ok))
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+def _run_hist(H, world, halo, worker=_hist_worker):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_hist_worker, args=(r, world, port, H, halo, q)) for r in range(world)]
+    procs = [ctx.Process(target=worker, args=(r, world, port, H, halo, q)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=120) for _ in range(world)]
@@ -136,6 +165,11 @@ def test_history_exchange_two_ranks():
 
 def test_history_exchange_halo_spans_several_strips():
     _run_hist(H=30, world=4, halo=11)  # strips of 7-8 rows: a halo reaches two neighbours on each side
+
+
+def test_halo_samples_arrive_between_the_two_render_phases():
+    _run_hist(H=40, world=2, halo=6, worker=_lean_worker)
+    _run_hist(H=30, world=4, halo=11, worker=_lean_worker)
 
 
 def test_history_transfer_plan_covers_every_halo_row_once():

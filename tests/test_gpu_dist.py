@@ -1,6 +1,7 @@
 """The N > 1 path end to end on one GPU: two ranks (gloo transport, both rendering on cuda:0) run the code bench.py runs
-per frame — render the strip + halo, exchange the halo rows' temporal history point-to-point, all-gather the image — and
-every gathered frame must equal the single-context frame bit for bit."""
+per frame — render the strip + halo (or, with trace_halo=False, trace the strip alone and receive the halo rows' sample
+means between the two render phases), exchange the halo rows' temporal history point-to-point, all-gather the image —
+and every gathered frame must equal the single-context frame bit for bit."""
 import os
 import socket
 
@@ -18,7 +19,7 @@ def _free_port():
     return p
 
 
-def _rank(rank, world, port, W, H, frames, q):
+def _rank(rank, world, port, W, H, frames, trace_halo, q):
     import torch
     import torch.distributed as tdist
     import lprt_amd
@@ -31,14 +32,13 @@ def _rank(rank, world, port, W, H, frames, q):
     wb, we = dist.window_rows(H, world, rank)
     r = lprt_amd.Renderer(W, H, abi.F32, device=0, row_begin=wb, row_end=we)
     r.set_stream(torch.cuda.current_stream().cuda_stream)
-    frame = dist.ShardedFrame(W, H, rank, world, torch.device("cuda", 0), backend="gloo")
-    r.set_output_target(*frame.target())
+    frame = dist.ShardedFrame(W, H, rank, world, torch.device("cuda", 0), backend="gloo", trace_halo=trace_halo)
+    frame.attach(r)
     r.load_scene(sc)
     out = []
     for _ in range(frames):
         r.set_scene(sc)
-        r.render(abi.default_settings(spp=1))
-        moved = frame.exchange_history(r)
+        moved = frame.render(r, abi.default_settings(spp=1))
         img = frame.all_gather()
         torch.cuda.synchronize()
         out.append(img.cpu().numpy().copy())
@@ -47,7 +47,8 @@ def _rank(rank, world, port, W, H, frames, q):
     tdist.destroy_process_group()
 
 
-def test_two_ranks_render_exchange_gather_equal_one_context():
+@pytest.mark.parametrize("trace_halo", [True, False])
+def test_two_ranks_render_exchange_gather_equal_one_context(trace_halo):
     import torch.multiprocessing as mp
     import lprt_amd
     from lprt_amd import abi, scenes
@@ -55,7 +56,7 @@ def test_two_ranks_render_exchange_gather_equal_one_context():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank, args=(r, world, port, W, H, frames, q)) for r in range(world)]
+    procs = [ctx.Process(target=_rank, args=(r, world, port, W, H, frames, trace_halo, q)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=300) for _ in range(world)]

@@ -320,6 +320,76 @@ def test_sharded_sequence_with_history_exchange_equals_single_gpu(cornell, prec)
 
 
 @pytest.mark.parametrize("prec", [abi.F32, abi.F16])
+@pytest.mark.parametrize("spp,gi", [(2, True), (1, False)])
+def test_strips_that_import_their_halo_samples_equal_single_gpu(cornell, prec, spp, gi):
+    """Sharding without redundant rays: every rank runs the per-sample stages on the rows it owns only
+    (lprt_set_sample_rows) and, between LPRT_PHASE_SAMPLE and LPRT_PHASE_RESOLVE, imports the sample means of its halo
+    rows (LPRT_HIST_SAMPLES) and last frame's history from their owners.  Frames equal the single-GPU frames bit for bit,
+    and the halo rows cast no rays."""
+    import torch
+    W, H, world, frames = 160, 300, 3, 3
+    full = lprt_amd.Renderer(W, H, prec)
+    full.load_scene(cornell)
+    wins = [dist.window_rows(H, world, r) for r in range(world)]
+    strips = [dist.strip_rows(H, world, r) for r in range(world)]
+    ranks = []
+    for (wb, we), (b, e) in zip(wins, strips):
+        r = lprt_amd.Renderer(W, H, prec, row_begin=wb, row_end=we)
+        r.load_scene(cornell)
+        r.set_sample_rows(b, e - b)
+        r.enable_counters(True)
+        ranks.append(r)
+    full.enable_counters(True)
+    groups = abi.HIST_ALL | abi.HIST_SAMPLES
+    row_bytes = ranks[0].history_row_bytes(groups)
+    assert row_bytes == W * ((65 + 32) if prec == abi.F32 else (33 + 16))
+    plan = dist.history_transfers(H, world)
+    for k in range(frames):
+        fs = abi.default_settings(spp=spp, gi_on=gi)
+        full.set_scene(cornell)
+        full.render(fs)
+        want = full.read("OUTPUT")
+        for r in ranks:
+            r.set_scene(cornell)
+            r.render_phase(fs, abi.PHASE_SAMPLE)
+        for src, dst, b, e in plan:
+            buf = torch.empty((e - b) * row_bytes, dtype=torch.uint8, device="cuda")
+            ranks[src].export_history_rows(b, e - b, buf.data_ptr(), groups)
+            ranks[src].synchronize()
+            ranks[dst].import_history_rows(b, e - b, buf.data_ptr(), groups)
+            ranks[dst].synchronize()
+        for r in ranks:
+            r.render_phase(fs, abi.PHASE_RESOLVE)
+        got = dist.assemble_strips([r.read("OUTPUT")[b - wb:e - wb] for r, (wb, we), (b, e) in zip(ranks, wins, strips)], H, world)
+        assert np.array_equal(got, want, equal_nan=True), f"frame {k}"
+    # shadow + GI rays of all ranks together = those of the full frame; only the primary rays cover the halo as well
+    for st in ("trace_di1", "trace_gi", "trace_di2"):
+        assert sum(r.stage_counters(st)["rays"] for r in ranks) == full.stage_counters(st)["rays"], st
+    assert sum(r.stage_counters("primary")["rays"] for r in ranks) == W * sum(we - wb for wb, we in wins) * frames
+
+
+def test_render_phases_and_sample_rows_are_checked(cornell):
+    r = lprt_amd.Renderer(64, 64, abi.F32, row_begin=8, row_end=40)
+    r.load_scene(cornell)
+    fs = abi.default_settings(spp=1)
+    with pytest.raises(lprt_amd.LprtError, match="out of order"):
+        r.render_phase(fs, abi.PHASE_RESOLVE)
+    r.render_phase(fs, abi.PHASE_SAMPLE)
+    with pytest.raises(lprt_amd.LprtError, match="out of order"):
+        r.render_phase(fs, abi.PHASE_SAMPLE)
+    r.render_phase(fs, abi.PHASE_RESOLVE)
+    with pytest.raises(lprt_amd.LprtError, match="unknown render phase"):
+        r.render_phase(fs, 3)
+    with pytest.raises(lprt_amd.LprtError, match="row window"):
+        r.set_sample_rows(0, 16)
+    with pytest.raises(lprt_amd.LprtError, match="row window"):
+        r.set_sample_rows(32, 16)
+    r.set_sample_rows(16, 8)
+    r.set_sample_rows(0, 0)  # back to the whole window
+    r.render(fs)
+
+
+@pytest.mark.parametrize("prec", [abi.F32, abi.F16])
 def test_moving_objects_and_camera_reproject_like_the_oracle(cornell, prec):
     """Temporal maps under motion (cuda.hpp:2265-2416): the tall box turns, the short box slides and the camera
     dollies between frames, so reprojection goes through last-frame L2W / W2C, history taps move and some are
