@@ -15,9 +15,11 @@ for prec, pn in ((abi.F32, "f32"), (abi.F16, "f16")):
     rank = world // 2
     own_b, own_e = lp_dist.strip_rows(H, world, rank)
     win_b, win_e = lp_dist.window_rows(H, world, rank)
-    for label, (b, e) in (("full", (0, H)), ("strip+halo", (win_b, win_e)), ("strip", (own_b, own_e))):
+    for label, (b, e) in (("full", (0, H)), ("strip+halo", (win_b, win_e)), ("halo untraced", (win_b, win_e)), ("strip", (own_b, own_e))):
         r = lprt_amd.Renderer(W, H, prec, device=0, row_begin=b, row_end=e)
         r.load_scene(sc)
+        if label == "halo untraced":  # what a rank computes by default: spp loop on the strip, everything else on the window
+            r.set_sample_rows(own_b, own_e - own_b)
         fs = abi.default_settings(spp=spp, gi_on=True, svgf=True)
         prepared = r.prepare_scene(sc)
         for _ in range(3):
@@ -28,5 +30,5 @@ for prec, pn in ((abi.F32, "f32"), (abi.F16, "f16")):
         for _ in range(n):
             r.set_scene(prepared=prepared); r.render(fs)
         r.synchronize()
-        print(f"{name} {W}x{H} {spp}spp {pn} world={world} {label:11s} rows={e-b:5d}  {1e3*(time.perf_counter()-t0)/n:8.3f} ms", flush=True)
+        print(f"{name} {W}x{H} {spp}spp {pn} world={world} {label:13s} rows={e-b:5d}  {1e3*(time.perf_counter()-t0)/n:8.3f} ms", flush=True)
         r.close()
