@@ -189,7 +189,7 @@ def pmc_traffic(kernel, prec):
 SAMPLE_STAGES = ("rng", "shade1", "shade2", "compose", "trace_di1", "trace_gi", "trace_di2")  # run on the sample rows only
 
 
-def roofline_of(res, prec, width, spp):
+def roofline_of(res, prec, width, spp, world=1):
     """Dominant kernel family (largest HIP-event time over the calibration frames) against the HBM roof; its launch
     duration is the live average over the timed region, where it is the only instrumented stage."""
     i = 0 if prec == abi.F32 else 1
@@ -219,7 +219,8 @@ def roofline_of(res, prec, width, spp):
         basis = "compulsory bytes/pixel x pixels (SURVEY.md 8(a))"
     achieved = bytes_per_launch / avg_s
     kernel = abi.STAGE_KERNELS.get(name, name)
-    traffic, traffic_src = pmc_traffic(kernel, prec)
+    # the committed PMC pass is of the N = 1 command: a strip's launches are not comparable
+    traffic, traffic_src = pmc_traffic(kernel, prec) if world == 1 else (None, "collected for N=1 only")
     return {"bound": "hbm", "kernel": kernel, "stage": name, "achieved": achieved / 1e9,
             "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
             "avg_launch_us": avg_s * 1e6, "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
@@ -323,8 +324,8 @@ def main():
                            "workload": f"{sc.name} {W}x{H} {spp}spp fp16 (BASELINE.json configs[2])",
                            "speedup_vs_f32": res16["mrays_per_s"] / res32["mrays_per_s"],
                            "stage_ms_per_frame": {k: v[0] for k, v in res16["calib"].items()},
-                           "roofline": roofline_of(res16, abi.F16, W, spp) if res16["stage"] else None}
-        out["roofline"] = roofline_of(res32, abi.F32, W, spp) if res32["stage"] else None
+                           "roofline": roofline_of(res16, abi.F16, W, spp, world) if res16["stage"] else None}
+        out["roofline"] = roofline_of(res32, abi.F32, W, spp, world) if res32["stage"] else None
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, spp)
         else:

@@ -47,12 +47,12 @@ def _rank(rank, world, port, W, H, frames, trace_halo, q):
     tdist.destroy_process_group()
 
 
-@pytest.mark.parametrize("trace_halo", [True, False])
-def test_two_ranks_render_exchange_gather_equal_one_context(trace_halo):
+@pytest.mark.parametrize("world,trace_halo", [(2, True), (2, False), (3, False)])  # 3 ranks: the middle one has two neighbours
+def test_ranks_render_exchange_gather_equal_one_context(world, trace_halo):
     import torch.multiprocessing as mp
     import lprt_amd
     from lprt_amd import abi, scenes
-    W, H, frames, world = 128, 288, 3, 2
+    W, H, frames = 128, 288, 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
