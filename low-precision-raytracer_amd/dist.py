@@ -15,8 +15,8 @@ camera needs none; pass a larger `halo` for fast vertical motion).
 
 `trace_halo=False` removes the redundant rays: a rank runs the per-sample stages (RNG, shade, shadow/GI rays) on the rows
 it OWNS only and, between the two render phases, receives the sample means of its halo rows from their owners together
-with the history of the previous frame -- still one point-to-point batch per frame, 32 B/pixel more (fp32).  At 4K / 8
-GPUs a rank traces 270 rows instead of 406.
+(32 B/pixel, fp32); the history of the previous frame travels under the sample phase.  At 4K / 8 GPUs a rank traces 270
+rows instead of 406.
 """
 import numpy as np
 
@@ -82,6 +82,7 @@ class ShardedFrame:
         self.begin, self.end = strip_rows(height, world_size, rank)
         self.win_begin, self.win_end = window_rows(height, world_size, rank, halo)
         self._hist = {}
+        self._hist_packed = False
         self.image = torch.zeros((height, width, 4), dtype=torch.float32, device=device)
         self.equal = equal_strips(height, world_size)
         self.max_rows = -(-height // world_size)
@@ -128,31 +129,59 @@ class ShardedFrame:
             renderer.set_sample_rows(self.begin, self.end - self.begin)
 
     def render(self, renderer, settings, stream_ordered=False):
-        """One sharded frame up to (not including) the all-gather; returns the bytes this rank exchanged."""
+        """One sharded frame up to (not including) the all-gather; returns the bytes this rank exchanged.
+
+        trace_halo=False: the history frame n-1 left was packed when that frame ended; its transfer is posted here, after
+        the caller's all-gather of frame n-1, and runs under the sample phase of frame n.  Only the sample means of frame
+        n (32 of the 97 B per pixel and row, fp32) travel between the two phases with the stream waiting for them."""
         from . import abi
+        if self.world == 1:
+            renderer.render(settings)
+            return 0
         if self.trace_halo:
             renderer.render(settings)
             return self.exchange_history(renderer, stream_ordered)
+        ordered = stream_ordered and self.backend == "nccl"
+        hist, samp = self._plan(renderer, "history"), self._plan(renderer, "samples")
+        in_flight = self._post(renderer, hist, ordered) if self._hist_packed else None
         renderer.render_phase(settings, abi.PHASE_SAMPLE)
-        moved = self.exchange_history(renderer, stream_ordered, samples=True)  # + the history the last frame left
+        self._export(renderer, samp)
+        moved = self._finish(renderer, samp, self._post(renderer, samp, ordered), ordered)
+        if in_flight is not None:
+            moved += self._finish(renderer, hist, in_flight, ordered)
         renderer.render_phase(settings, abi.PHASE_RESOLVE)
+        self._export(renderer, hist)  # for the next frame
+        self._hist_packed = True
         return moved
+
+    def reset(self):
+        """Call with renderer.reset_history(): the history packed after the last frame is dropped with it."""
+        self._hist_packed = False
 
     def exchange_history(self, renderer, stream_ordered=False, samples=False):
         """Owned rows -> the neighbours that hold them as halo, halo rows <- their owners.  The SVGF history (and with
         samples=True this frame's sample means) travel for the whole halo, the TAA history for TAA_ROWS (+ motion margin)
         rows.  stream_ordered=True: the renderer enqueues on torch's current stream and the transport is NCCL, which
         orders itself after that stream — no host synchronisation is needed."""
-        import torch.distributed as dist
-        from . import abi
-        torch = self.torch
         if self.world == 1:
             return 0
-        if samples not in self._hist:
+        plan = self._plan(renderer, "history+samples" if samples else "history")
+        ordered = stream_ordered and self.backend == "nccl"
+        self._export(renderer, plan)
+        return self._finish(renderer, plan, self._post(renderer, plan, ordered), ordered)
+
+    # ---- the exchange in steps: plan (buffers, once) -> export (pack kernels) -> post (isend/irecv) -> finish (wait, unpack)
+    def _plan(self, renderer, what):
+        from . import abi
+        torch = self.torch
+        if what not in self._hist:
             staged = self.backend != "nccl"
-            plan = self._hist[samples] = []
+            plan = self._hist[what] = []
             taa_halo = min(self.halo, TAA_ROWS + max(0, self.halo - HALO_ROWS))
-            for groups, halo in ((abi.HIST_FILTER | (abi.HIST_SAMPLES if samples else 0), self.halo), (abi.HIST_TAA, taa_halo)):
+            group_halos = {"history": ((abi.HIST_FILTER, self.halo), (abi.HIST_TAA, taa_halo)),
+                           "history+samples": ((abi.HIST_FILTER | abi.HIST_SAMPLES, self.halo), (abi.HIST_TAA, taa_halo)),
+                           "samples": ((abi.HIST_SAMPLES, self.halo),)}[what]
+            for groups, halo in group_halos:
                 row_bytes = renderer.history_row_bytes(groups)
                 for src, dst, b, e in history_transfers(self.H, self.world, halo):
                     if self.rank not in (src, dst) or not (self.win_begin <= b and e <= self.win_end):
@@ -160,14 +189,18 @@ class ShardedFrame:
                     dev = torch.empty((e - b) * row_bytes, dtype=torch.uint8, device=self.device)
                     host = torch.empty((e - b) * row_bytes, dtype=torch.uint8) if staged and dev.is_cuda else None
                     plan.append((groups, src, dst, b, e, dev, host))
-        plan = self._hist[samples]
+        return self._hist[what]
+
+    def _export(self, renderer, plan):
         for groups, src, dst, b, e, dev, host in plan:
             if src == self.rank:
                 renderer.export_history_rows(b, e - b, dev.data_ptr(), groups)
-        ordered = stream_ordered and self.backend == "nccl"
+
+    def _post(self, renderer, plan, ordered):
+        import torch.distributed as dist
         if not ordered:
             renderer.synchronize()  # the exports run on the renderer's stream, the transport on torch's
-        ops, moved = [], 0
+        ops = []
         for groups, src, dst, b, e, dev, host in plan:
             if src == self.rank:
                 if host is not None:
@@ -175,12 +208,17 @@ class ShardedFrame:
                 ops.append(dist.P2POp(dist.isend, host if host is not None else dev, dst))
             else:
                 ops.append(dist.P2POp(dist.irecv, host if host is not None else dev, src))
-            moved += dev.numel()
-        for req in dist.batch_isend_irecv(ops):
+        return dist.batch_isend_irecv(ops) if ops else []
+
+    def _finish(self, renderer, plan, reqs, ordered):
+        torch = self.torch
+        for req in reqs:
             req.wait()
-        if not ordered and self.torch.cuda.is_available() and str(self.device).startswith("cuda"):
+        if not ordered and torch.cuda.is_available() and str(self.device).startswith("cuda"):
             torch.cuda.synchronize()
+        moved = 0
         for groups, src, dst, b, e, dev, host in plan:
+            moved += dev.numel()
             if dst == self.rank:
                 if host is not None:
                     dev.copy_(host)

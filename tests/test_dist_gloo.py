@@ -67,23 +67,39 @@ def test_all_gather_ragged_strips():
 
 # ---- temporal-history halo exchange --------------------------------------------------------
 class _FakeRenderer:
-    """Stands in for lprt_export/import_history_rows on CPU: one 'plane' of ROW_BYTES bytes per image row; rows a
-    rank owns carry a value derived from (row, frame), halo rows carry garbage until imported."""
+    """Stands in for lprt_export/import_history_rows on CPU: per group (filter history 1, TAA history 2, sample means 4)
+    one 'plane' of ROW_BYTES bytes per image row; rows a rank owns carry a value derived from (group, row, frame), halo
+    rows carry garbage until imported."""
     ROW_BYTES = 24
+    GROUPS = (1, 2, 4)
 
     def __init__(self, frame):
         self.f = frame
-        self.rows = {}
+        self.planes = {g: {} for g in self.GROUPS}
+        self.resolved_ok = True
 
-    def render(self, k):
+    @staticmethod
+    def value(g, row, k):
+        return (row * 7 + k * 3 + g) % 251
+
+    def _fill(self, g, k):
         for r in range(self.f.win_begin, self.f.win_end):
             owned = self.f.begin <= r < self.f.end
-            self.rows[r] = np.full(self.ROW_BYTES, (r * 7 + k) % 251 if owned else 255, dtype=np.uint8)
+            self.planes[g][r] = np.full(self.ROW_BYTES, self.value(g, r, k) if owned else 255, dtype=np.uint8)
 
-    def history_row_bytes(self, groups=3):
-        return self.ROW_BYTES
+    def _holds(self, g, k, reach):
+        rows = range(max(self.f.win_begin, self.f.begin - reach), min(self.f.win_end, self.f.end + reach))
+        return all(bool((self.planes[g][r] == self.value(g, r, k)).all()) for r in rows)
 
-    # the two-phase frame of trace_halo=False: the resolve phase must find every row of the window filled by its owner
+    def render(self, k):  # a whole frame: leaves history on the owned rows
+        self._fill(1, k)
+        self._fill(2, k)
+
+    def history_ok(self, k):  # filter history on the whole window, TAA history on the rows next to the strip
+        return self._holds(1, k, self.f.halo) and self._holds(2, k, min(self.f.halo, dist.TAA_ROWS + max(0, self.f.halo - dist.HALO_ROWS)))
+
+    # the two-phase frame of trace_halo=False: the resolve phase must find this frame's sample means on every row of the
+    # window and (from frame 1 on) the history the last frame left
     def set_output_target(self, *a):
         pass
 
@@ -92,24 +108,31 @@ class _FakeRenderer:
 
     def render_phase(self, k, phase):
         if phase == 1:
-            self.render(k)
+            self._fill(4, k)
         else:
-            self.resolved_ok = all(bool((self.rows[row] == (row * 7 + k) % 251).all()) for row in range(self.f.win_begin, self.f.win_end))
+            self.resolved_ok = self.resolved_ok and self._holds(4, k, self.f.halo) and (k == 0 or self.history_ok(k - 1))
+            self.render(k)
+
+    def history_row_bytes(self, groups=3):
+        return self.ROW_BYTES * sum(1 for g in self.GROUPS if groups & g)
 
     def synchronize(self):
         pass
 
     def export_history_rows(self, first, n, ptr, groups=3):
         import ctypes
-        buf = (ctypes.c_uint8 * (n * self.ROW_BYTES)).from_address(ptr)
-        np.frombuffer(buf, dtype=np.uint8)[:] = np.concatenate([self.rows[first + i] for i in range(n)])
+        gs = [g for g in self.GROUPS if groups & g]
+        buf = (ctypes.c_uint8 * (n * self.ROW_BYTES * len(gs))).from_address(ptr)
+        np.frombuffer(buf, dtype=np.uint8)[:] = np.concatenate([self.planes[g][first + i] for g in gs for i in range(n)])
 
     def import_history_rows(self, first, n, ptr, groups=3):
         import ctypes
-        buf = (ctypes.c_uint8 * (n * self.ROW_BYTES)).from_address(ptr)
-        a = np.frombuffer(buf, dtype=np.uint8).reshape(n, self.ROW_BYTES)
-        for i in range(n):
-            self.rows[first + i] = a[i].copy()
+        gs = [g for g in self.GROUPS if groups & g]
+        buf = (ctypes.c_uint8 * (n * self.ROW_BYTES * len(gs))).from_address(ptr)
+        a = np.frombuffer(buf, dtype=np.uint8).reshape(len(gs), n, self.ROW_BYTES)
+        for j, g in enumerate(gs):
+            for i in range(n):
+                self.planes[g][first + i] = a[j, i].copy()
 
 
 def _hist_worker(rank, world, port, H, halo, q):
@@ -122,8 +145,7 @@ def _hist_worker(rank, world, port, H, halo, q):
     for k in range(3):
         r.render(k)
         frame.exchange_history(r)
-        for row in range(frame.win_begin, frame.win_end):  # every row of the window now holds its OWNER's value
-            ok = ok and bool((r.rows[row] == (row * 7 + k) % 251).all())
+        ok = ok and r.history_ok(k)  # every halo row now holds its OWNER's value
     q.put((rank, ok))
     tdist.barrier()
     tdist.destroy_process_group()
@@ -137,8 +159,10 @@ def _lean_worker(rank, world, port, H, halo, q):
     r = _FakeRenderer(frame)
     frame.attach(r)
     ok = r.sample_rows == (frame.begin, frame.end - frame.begin)
-    for k in range(3):
-        moved = frame.render(r, k)  # sample phase -> exchange (history + samples in one batch) -> resolve phase
+    for k in range(4):
+        # sample phase (last frame's history in flight) -> sample means -> resolve phase -> history packed for the next frame
+        moved = frame.render(r, k)
+        frame.all_gather()
         ok = ok and r.resolved_ok and moved > 0
     q.put((rank, ok))
     tdist.barrier()
