@@ -10,6 +10,7 @@
 // filtered by the same thread: w_z, w_n and h are evaluated once per tap and shared; only w_l differs.
 // Colour and variance of a lobe travel as one {r,g,b,var} vector (one load per tap).
 #include "kernels.hpp"
+#include <cstdlib>
 #include "shade.hpp"
 
 namespace lprt {
@@ -93,8 +94,12 @@ template <typename T> __global__ void __launch_bounds__(256) k_depth_gradient(Fr
 // One workgroup = a 32x8 pixel tile; the (32+8)x(8+8) input window of both lobes is staged in LDS once (5 loads per
 // thread instead of 162) and the 81 taps are LDS reads, accumulated in the reference's order (x outer, y inner).
 constexpr int TC_BX = 32, TC_BY = 8, TC_R = 4, TC_TW = TC_BX + 2 * TC_R, TC_TH = TC_BY + 2 * TC_R;
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+struct H16x4 { // a V4<h16> as two packed pairs
+    h16x2 xy, zw;
+};
 template <typename T>
-__global__ void __launch_bounds__(256) k_temporal_color(FrameDev<T> fb, T color_w) {
+__global__ void __launch_bounds__(256) k_temporal_color(FrameDev<T> fb, T color_w, int always_test) {
     __shared__ V4<T> tile[2][TC_TH][TC_TW];
     __shared__ uint32_t s_nonfinite; // some staged colour component is inf / NaN: the window sums must test every sample
     const int W = (int)fb.win.W, R = (int)fb.win.rows();
@@ -118,8 +123,8 @@ __global__ void __launch_bounds__(256) k_temporal_color(FrameDev<T> fb, T color_
     if (__builtin_amdgcn_ballot_w64(bad) && (threadIdx.x & 63) == 0)
         atomicOr(&s_nonfinite, 1u);
     __syncthreads();
-    // workgroup-uniform; single precision only: in half the tested form was measured faster (0.20 vs 0.29 ms)
-    const bool all_finite = sizeof(T) == 4 && s_nonfinite == 0u;
+    // workgroup-uniform (LPRT_SVGF_ALWAYS_TEST=1 forces the per-sample tests for A/B runs)
+    const bool all_finite = s_nonfinite == 0u && !always_test;
     const int px = (int)blockIdx.x * TC_BX + tx, py = (int)blockIdx.y * TC_BY + ty;
     if (px >= W || py >= R)
         return;
@@ -134,6 +139,30 @@ __global__ void __launch_bounds__(256) k_temporal_color(FrameDev<T> fb, T color_
             // every sample of the window counts: the same sums in the same order without the per-sample tests; the
             // sample count is a small integer, exact in either precision
             int cnt = 0;
+            if constexpr (sizeof(T) == 2) {
+                // half: the same adds and multiplies, two channels per v_pk_add_f16 / v_pk_mul_f16 (each half of a packed
+                // operation rounds on its own, exactly like the scalar one; the w pair rides along unused)
+                h16x2 a_xy = {(h16)0, (h16)0}, a_zw = a_xy, b_xy = a_xy, b_zw = a_xy;
+                for (int i = -4; i <= 4; i++) {
+                    int qx = px + i;
+                    if (qx < 0 || qx >= W)
+                        continue;
+#pragma unroll
+                    for (int j = -4; j <= 4; j++) {
+                        int qy = py + j;
+                        if (qy < 0 || qy >= R)
+                            continue;
+                        const H16x4 q = __builtin_bit_cast(H16x4, tile[l][ty + TC_R + j][tx + TC_R + i]);
+                        cnt++;
+                        a_xy = a_xy + q.xy;
+                        b_xy = b_xy + q.xy * q.xy;
+                        a_zw = a_zw + q.zw;
+                        b_zw = b_zw + q.zw * q.zw;
+                    }
+                }
+                m1 = mk3((T)a_xy.x, (T)a_xy.y, (T)a_zw.x);
+                m2 = mk3((T)b_xy.x, (T)b_xy.y, (T)b_zw.x);
+            } else
             for (int i = -4; i <= 4; i++) {
                 int qx = px + i;
                 if (qx < 0 || qx >= W)
@@ -490,7 +519,8 @@ template <typename T> void launch_depth_gradient(hipStream_t st, const FrameDev<
 }
 template <typename T> void launch_temporal_color(hipStream_t st, const FrameDev<T> &fb, float color_w) {
     dim3 grid((fb.win.W + TC_BX - 1) / TC_BX, (fb.win.rows() + TC_BY - 1) / TC_BY);
-    hipLaunchKernelGGL(k_temporal_color<T>, grid, dim3(256), 0, st, fb, (T)color_w);
+    const int always_test = std::getenv("LPRT_SVGF_ALWAYS_TEST") != nullptr; // read per launch: tests flip it
+    hipLaunchKernelGGL(k_temporal_color<T>, grid, dim3(256), 0, st, fb, (T)color_w, always_test);
 }
 template <typename T> void launch_moments(hipStream_t st, const FrameDev<T> &fb, float moments_w) {
     hipLaunchKernelGGL(k_moments<T>, grid_for(fb.win.npix()), dim3(256), 0, st, fb, (T)moments_w);

@@ -522,6 +522,30 @@ def test_axis_rejections_never_change_a_frame(sponza, prec, monkeypatch):
         assert np.array_equal(a, b, equal_nan=True)
 
 
+@pytest.mark.parametrize("prec", [abi.F32, abi.F16])
+@pytest.mark.parametrize("scene_name", ["cornell", "textured"])
+def test_untested_window_sums_of_the_temporal_filter_never_change_a_frame(scene_name, prec, monkeypatch):
+    """k_temporal_color sums its 9x9 window without the per-sample finite tests when a workgroup's staged tile holds no
+    inf/NaN (in half with packed adds/multiplies, two channels per instruction).  Forcing the tested form
+    (LPRT_SVGF_ALWAYS_TEST) must give bit-identical lobes and frames over three frames."""
+    sc = scenes.SCENES[scene_name]()
+    outs = []
+    for forced in (False, True):
+        if forced:
+            monkeypatch.setenv("LPRT_SVGF_ALWAYS_TEST", "1")
+        else:
+            monkeypatch.delenv("LPRT_SVGF_ALWAYS_TEST", raising=False)
+        r = lprt_amd.Renderer(200, 120, prec)
+        r.load_scene(sc)
+        for _ in range(3):
+            r.set_scene(sc)
+            r.render(abi.default_settings(spp=2))
+        outs.append((r.read("OUTPUT"), r.read("MUL_GI_COLORED"), r.read("MUL_GI_WHITE")))
+        r.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b, equal_nan=True)
+
+
 @pytest.mark.parametrize("scene_name", ["cornell", "small_test"])
 def test_reusing_round0_shadow_rays_gives_the_same_frames(scene_name):
     """lprt_frame_settings.reuse_direct_light: the shadow rays of round 0 do not depend on the sample, so casting them for
