@@ -94,9 +94,9 @@ template <typename T> __global__ void __launch_bounds__(256) k_depth_gradient(Fr
 // One workgroup = a 32x8 pixel tile; the (32+8)x(8+8) input window of both lobes is staged in LDS once (5 loads per
 // thread instead of 162) and the 81 taps are LDS reads, accumulated in the reference's order (x outer, y inner).
 constexpr int TC_BX = 32, TC_BY = 8, TC_R = 4, TC_TW = TC_BX + 2 * TC_R, TC_TH = TC_BY + 2 * TC_R;
-typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
-struct H16x4 { // a V4<h16> as two packed pairs
-    h16x2 xy, zw;
+template <typename T> struct PackedV4 { // a V4<T> as two pairs for packed arithmetic
+    typedef T v2 __attribute__((ext_vector_type(2)));
+    v2 xy, zw;
 };
 template <typename T>
 __global__ void __launch_bounds__(256) k_temporal_color(FrameDev<T> fb, T color_w, int always_test) {
@@ -139,30 +139,10 @@ __global__ void __launch_bounds__(256) k_temporal_color(FrameDev<T> fb, T color_
             // every sample of the window counts: the same sums in the same order without the per-sample tests; the
             // sample count is a small integer, exact in either precision
             int cnt = 0;
-            if constexpr (sizeof(T) == 2) {
-                // half: the same adds and multiplies, two channels per v_pk_add_f16 / v_pk_mul_f16 (each half of a packed
-                // operation rounds on its own, exactly like the scalar one; the w pair rides along unused)
-                h16x2 a_xy = {(h16)0, (h16)0}, a_zw = a_xy, b_xy = a_xy, b_zw = a_xy;
-                for (int i = -4; i <= 4; i++) {
-                    int qx = px + i;
-                    if (qx < 0 || qx >= W)
-                        continue;
-#pragma unroll
-                    for (int j = -4; j <= 4; j++) {
-                        int qy = py + j;
-                        if (qy < 0 || qy >= R)
-                            continue;
-                        const H16x4 q = __builtin_bit_cast(H16x4, tile[l][ty + TC_R + j][tx + TC_R + i]);
-                        cnt++;
-                        a_xy = a_xy + q.xy;
-                        b_xy = b_xy + q.xy * q.xy;
-                        a_zw = a_zw + q.zw;
-                        b_zw = b_zw + q.zw * q.zw;
-                    }
-                }
-                m1 = mk3((T)a_xy.x, (T)a_xy.y, (T)a_zw.x);
-                m2 = mk3((T)b_xy.x, (T)b_xy.y, (T)b_zw.x);
-            } else
+            // two channels per instruction (v_pk_add/mul_f16, v_pk_add/mul_f32): each lane of a packed operation is an
+            // IEEE operation of its own, rounded like the scalar one; the w channel rides along unused
+            typedef typename PackedV4<T>::v2 v2;
+            v2 a_xy = {zero, zero}, a_zw = a_xy, b_xy = a_xy, b_zw = a_xy;
             for (int i = -4; i <= 4; i++) {
                 int qx = px + i;
                 if (qx < 0 || qx >= W)
@@ -172,16 +152,16 @@ __global__ void __launch_bounds__(256) k_temporal_color(FrameDev<T> fb, T color_
                     int qy = py + j;
                     if (qy < 0 || qy >= R)
                         continue;
-                    const V4<T> q = tile[l][ty + TC_R + j][tx + TC_R + i];
+                    const PackedV4<T> q = __builtin_bit_cast(PackedV4<T>, tile[l][ty + TC_R + j][tx + TC_R + i]);
                     cnt++;
-                    m1.x = m1.x + q.x;
-                    m2.x = m2.x + q.x * q.x;
-                    m1.y = m1.y + q.y;
-                    m2.y = m2.y + q.y * q.y;
-                    m1.z = m1.z + q.z;
-                    m2.z = m2.z + q.z * q.z;
+                    a_xy = a_xy + q.xy;
+                    b_xy = b_xy + q.xy * q.xy;
+                    a_zw = a_zw + q.zw;
+                    b_zw = b_zw + q.zw * q.zw;
                 }
             }
+            m1 = mk3((T)a_xy.x, (T)a_xy.y, (T)a_zw.x);
+            m2 = mk3((T)b_xy.x, (T)b_xy.y, (T)b_zw.x);
             wt = mk3(cvt<T>((float)cnt), cvt<T>((float)cnt), cvt<T>((float)cnt));
         } else {
             for (int i = -4; i <= 4; i++) {
