@@ -10,10 +10,7 @@ void launch_trace_rays(hipStream_t st, const SceneDev<T> &sc, const lprt_ray *ra
 template <typename T>
 void launch_make_objrecs(hipStream_t st, const ObjSlot<T> *slots, const ObjConst<T> *objects, const BlasInfo *blas, const T *roots, uint32_t n,
                          uint32_t n_vaos, ObjRec<T> *out);
-template <typename T> void launch_convert_objects(hipStream_t st, const lprt_object *in, ObjConst<T> *out, uint32_t n);
 template <typename T> void launch_convert_materials(hipStream_t st, const lprt_material *in, MaterialT<T> *out, uint32_t n);
-template <typename T> void launch_convert_lights(hipStream_t st, const lprt_light *in, LightT<T> *out, uint32_t n);
-template <typename T> void launch_convert_mat4(hipStream_t st, const float *in, M4<T> *out, uint32_t n);
 // up to LPRT_MAX_COPY_JOBS flat device-to-device byte copies in one launch (history-plane pack / unpack)
 #define LPRT_MAX_COPY_JOBS 12
 struct CopyJobs {

@@ -53,15 +53,7 @@ void launch_trace_rays(hipStream_t st, const SceneDev<T> &sc, const lprt_ray *ra
 template void launch_trace_rays<float>(hipStream_t, const SceneDev<float> &, const lprt_ray *, uint32_t, bool, lprt_hit *, Counters *);
 template void launch_trace_rays<h16>(hipStream_t, const SceneDev<h16> &, const lprt_ray *, uint32_t, bool, lprt_hit *, Counters *);
 
-// ---- scene constant conversion (CUDAObjectConstantData / CUDAMaterial / RDLight in DataT) -------------
-template <typename T> __global__ void k_convert_objects(const lprt_object *in, ObjConst<T> *out, uint32_t n) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n)
-        return;
-    ObjConst<T> o;
-    convert_object(in[i], o);
-    out[i] = o;
-}
+// ---- material conversion (CUDAMaterial in DataT); objects and lights are converted by k_build_tlas (scene_dev.hpp) ----
 template <typename T> __global__ void k_convert_materials(const lprt_material *in, MaterialT<T> *out, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
@@ -79,21 +71,6 @@ template <typename T> __global__ void k_convert_materials(const lprt_material *i
     m.pad = 0;
     out[i] = m;
 }
-template <typename T> __global__ void k_convert_lights(const lprt_light *in, LightT<T> *out, uint32_t n) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n)
-        return;
-    LightT<T> l;
-    convert_light(in[i], l);
-    out[i] = l;
-}
-template <typename T> __global__ void k_convert_mat4(const float *in, M4<T> *out, uint32_t n) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * 16)
-        return;
-    out[i / 16].m[i % 16] = cvt<T>(in[i]);
-}
-
 // ObjRec[s] for TLAS slot s, gathered once per scene/BLAS change
 template <typename T>
 __global__ void k_make_objrecs(const ObjSlot<T> *slots, const ObjConst<T> *objects, const BlasInfo *blas, const T *roots, uint32_t n, uint32_t n_vaos,
@@ -112,21 +89,9 @@ void launch_make_objrecs(hipStream_t st, const ObjSlot<T> *slots, const ObjConst
         hipLaunchKernelGGL(k_make_objrecs<T>, dim3((n + 63) / 64), dim3(64), 0, st, slots, objects, blas, roots, n, n_vaos, out);
 }
 
-template <typename T> void launch_convert_objects(hipStream_t st, const lprt_object *in, ObjConst<T> *out, uint32_t n) {
-    if (n)
-        hipLaunchKernelGGL(k_convert_objects<T>, dim3((n + 63) / 64), dim3(64), 0, st, in, out, n);
-}
 template <typename T> void launch_convert_materials(hipStream_t st, const lprt_material *in, MaterialT<T> *out, uint32_t n) {
     if (n)
         hipLaunchKernelGGL(k_convert_materials<T>, dim3((n + 63) / 64), dim3(64), 0, st, in, out, n);
-}
-template <typename T> void launch_convert_lights(hipStream_t st, const lprt_light *in, LightT<T> *out, uint32_t n) {
-    if (n)
-        hipLaunchKernelGGL(k_convert_lights<T>, dim3((n + 63) / 64), dim3(64), 0, st, in, out, n);
-}
-template <typename T> void launch_convert_mat4(hipStream_t st, const float *in, M4<T> *out, uint32_t n) {
-    if (n)
-        hipLaunchKernelGGL(k_convert_mat4<T>, dim3((n * 16 + 63) / 64), dim3(64), 0, st, in, out, n);
 }
 // blockIdx.y = job; 16-byte words when both ends and the length allow it, bytes otherwise (uint8 planes, odd widths)
 __global__ void k_copy_jobs(CopyJobs jobs) {
@@ -169,10 +134,7 @@ void launch_sample_texture(hipStream_t st, const Texture *textures, const float 
 #define INST(T)                                                                                                        \
     template void launch_make_objrecs<T>(hipStream_t, const ObjSlot<T> *, const ObjConst<T> *, const BlasInfo *, const T *, uint32_t, uint32_t,    \
                                          ObjRec<T> *);                                                                 \
-    template void launch_convert_objects<T>(hipStream_t, const lprt_object *, ObjConst<T> *, uint32_t);                \
-    template void launch_convert_materials<T>(hipStream_t, const lprt_material *, MaterialT<T> *, uint32_t);           \
-    template void launch_convert_lights<T>(hipStream_t, const lprt_light *, LightT<T> *, uint32_t);                    \
-    template void launch_convert_mat4<T>(hipStream_t, const float *, M4<T> *, uint32_t);
+    template void launch_convert_materials<T>(hipStream_t, const lprt_material *, MaterialT<T> *, uint32_t);
 INST(float)
 INST(h16)
 #undef INST
