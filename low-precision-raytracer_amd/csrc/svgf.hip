@@ -295,7 +295,7 @@ __global__ void __launch_bounds__(256) k_moments(FrameDev<T> fb, T moments_w) {
 constexpr int WV_BX = 64, WV_BY = 4;
 template <typename T, int STRIDE>
 __global__ void __launch_bounds__(256) k_wavelet(FrameDev<T> fb, const V4<T> *in0, V4<T> *out0, const V4<T> *in1, V4<T> *out1, const T *vin0, T *vout0,
-                                                 const T *vin1, T *vout1) {
+                                                 const T *vin1, T *vout1, int always_test) {
     constexpr int TW = WV_BX + 4 * STRIDE, TH = WV_BY + 4;
     // fp32 at strides 8 and 16: four staged planes (56 B per texel) leave room for only 3 / 2 workgroups per CU, and
     // the kernel is latency-bound; there the colour planes are read straight from L1/L2 (rows are still contiguous
@@ -303,11 +303,20 @@ __global__ void __launch_bounds__(256) k_wavelet(FrameDev<T> fb, const V4<T> *in
     constexpr bool LDS_COLOR = sizeof(T) == 2 || STRIDE < LPRT_WV_LDS_BELOW;
     __shared__ V4<T> s_nd[TH][TW], s_c0[LDS_COLOR ? TH : 1][LDS_COLOR ? TW : 1], s_c1[LDS_COLOR ? TH : 1][LDS_COLOR ? TW : 1];
     __shared__ V2<T> s_il[TH][TW];
+    __shared__ uint32_t s_nonfinite; // some staged colour / variance is inf or NaN: the taps must test every sample
     const int W = (int)fb.win.W, R = (int)fb.win.rows();
     const int tx = (int)(threadIdx.x % WV_BX), ty = (int)(threadIdx.x / WV_BX);
     const int oy = (int)(blockIdx.y % STRIDE), by = (int)(blockIdx.y / STRIDE);
     const int x0 = (int)blockIdx.x * WV_BX - 2 * STRIDE; // image x of tile column 0
     const int r0 = WV_BY * by - 2;                        // lattice row of tile row 0
+    // in single precision the one-test form measured 2 % slower than the tested one (0.649 vs 0.633 ms): half only
+    constexpr bool FAST = LDS_COLOR && sizeof(T) == 2;
+    if (FAST) {
+        if (threadIdx.x == 0)
+            s_nonfinite = 0u;
+        __syncthreads();
+    }
+    bool bad = false;
     for (int e = (int)threadIdx.x; e < TW * TH; e += 256) {
         const int lx = e % TW, ly = e / TW;
         const int gx = x0 + lx, gy = oy + STRIDE * (r0 + ly);
@@ -315,13 +324,22 @@ __global__ void __launch_bounds__(256) k_wavelet(FrameDev<T> fb, const V4<T> *in
             const uint32_t q = (uint32_t)(gy * W + gx);
             s_nd[ly][lx] = fb.g_normal_depth[q];
             if (LDS_COLOR) {
-                s_c0[ly][lx] = in0[q];
-                s_c1[ly][lx] = in1[q];
+                const V4<T> c0 = in0[q], c1 = in1[q];
+                s_c0[ly][lx] = c0;
+                s_c1[ly][lx] = c1;
+                if (FAST)
+                    bad = bad || !(tfinite(c0.x) && tfinite(c0.y) && tfinite(c0.z) && tfinite(c0.w) && tfinite(c1.x) && tfinite(c1.y) &&
+                                   tfinite(c1.z) && tfinite(c1.w));
             }
             s_il[ly][lx] = V2<T>{fb.lobe[0].illum[q], fb.lobe[1].illum[q]};
         }
     }
+    if (FAST && __builtin_amdgcn_ballot_w64(bad) && (threadIdx.x & 63) == 0)
+        atomicOr(&s_nonfinite, 1u);
     __syncthreads();
+    // workgroup-uniform: with every staged sample finite, a tap needs one test (its own weight) instead of six, both
+    // weight sums coincide and colour + variance accumulate as two packed pairs
+    const bool all_finite = FAST && !always_test && s_nonfinite == 0u;
     const int px = (int)blockIdx.x * WV_BX + tx, py = oy + STRIDE * (WV_BY * by + ty);
     if (px >= W || py >= R)
         return;
@@ -365,42 +383,91 @@ __global__ void __launch_bounds__(256) k_wavelet(FrameDev<T> fb, const V4<T> *in
     const T illum_p[2] = {il_p.x, il_p.y};
     T nvar[2] = {zero, zero}, wv[2] = {zero, zero}, wc[2] = {zero, zero};
     V3<T> ncol[2] = {zero3<T>(), zero3<T>()};
+    if (all_finite) {
+        typedef typename PackedV4<T>::v2 v2;
+        v2 acc_xy[2] = {{zero, zero}, {zero, zero}}, acc_zw[2] = {{zero, zero}, {zero, zero}}; // colour x y | colour z, variance
+        T wsum[2] = {zero, zero};
 #pragma unroll
-    for (int i = -2; i <= 2; i++) {
-        int qx = px + STRIDE * i;
-        if (qx < 0 || qx >= W)
-            continue;
-#pragma unroll
-        for (int j = -2; j <= 2; j++) {
-            int qy = py + STRIDE * j;
-            if (qy < 0 || qy >= R)
+        for (int i = -2; i <= 2; i++) {
+            int qx = px + STRIDE * i;
+            if (qx < 0 || qx >= W)
                 continue;
-            const int lx = cx + STRIDE * i, ly = cy + j;
-            T h = hk[i < 0 ? -i : i] * hk[j < 0 ? -j : j];
-            const V4<T> nd_q = s_nd[ly][lx];
-            T w_z, w_n;
-            geo_weights(nd_p.w, nd_q.w, grad, cvt<T>((float)(STRIDE * i)), cvt<T>((float)(STRIDE * j)), xyz(nd_p), xyz(nd_q), w_z, w_n);
-            T wzn = w_z * w_n;
-            const V2<T> il_q = s_il[ly][lx];
-            const T iq[2] = {il_q.x, il_q.y};
 #pragma unroll
-            for (int l = 0; l < 2; l++) {
-                float num = -(float)tabs(illum_p[l] - iq[l]);
+            for (int j = -2; j <= 2; j++) {
+                int qy = py + STRIDE * j;
+                if (qy < 0 || qy >= R)
+                    continue;
+                const int lx = cx + STRIDE * i, ly = cy + j;
+                T h = hk[i < 0 ? -i : i] * hk[j < 0 ? -j : j];
+                const V4<T> nd_q = s_nd[ly][lx];
+                T w_z, w_n;
+                geo_weights(nd_p.w, nd_q.w, grad, cvt<T>((float)(STRIDE * i)), cvt<T>((float)(STRIDE * j)), xyz(nd_p), xyz(nd_q), w_z, w_n);
+                T wzn = w_z * w_n;
+                const V2<T> il_q = s_il[ly][lx];
+                const T iq[2] = {il_q.x, il_q.y};
+#pragma unroll
+                for (int l = 0; l < 2; l++) {
+                    float num = -(float)tabs(illum_p[l] - iq[l]);
 #ifdef LPRT_EXACT_SVGF_MATH
-                T w_l = cvt<T>(svgf_exp(svgf_div(num, den_l[l])));
+                    T w_l = cvt<T>(svgf_exp(svgf_div(num, den_l[l])));
 #else
-                T w_l = cvt<T>(__builtin_amdgcn_exp2f(num * k_l[l]));
+                    T w_l = cvt<T>(__builtin_amdgcn_exp2f(num * k_l[l]));
 #endif
-                T hw = h * (wzn * w_l);
-                if (tfinite(hw)) {
-                    const V4<T> cq = LDS_COLOR ? (l == 0 ? s_c0[ly][lx] : s_c1[ly][lx]) : in[l][(uint32_t)(qy * W + qx)];
-                    if (tfinite(cq.w)) {
-                        nvar[l] = nvar[l] + hw * hw * cq.w;
-                        wv[l] = wv[l] + hw;
+                    T hw = h * (wzn * w_l);
+                    if (tfinite(hw)) {
+                        const PackedV4<T> cq = __builtin_bit_cast(PackedV4<T>, l == 0 ? s_c0[LDS_COLOR ? ly : 0][LDS_COLOR ? lx : 0] : s_c1[LDS_COLOR ? ly : 0][LDS_COLOR ? lx : 0]);
+                        const v2 hh = {hw, hw}, hq = {hw, hw * hw};
+                        acc_xy[l] = acc_xy[l] + hh * cq.xy;
+                        acc_zw[l] = acc_zw[l] + hq * cq.zw; // hw * z | (hw * hw) * variance
+                        wsum[l] = wsum[l] + hw;
                     }
-                    if (tfinite(cq.x) && tfinite(cq.y) && tfinite(cq.z)) {
-                        ncol[l] = ncol[l] + hw * xyz(cq);
-                        wc[l] = wc[l] + hw;
+                }
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < 2; l++) {
+            ncol[l] = mk3((T)acc_xy[l].x, (T)acc_xy[l].y, (T)acc_zw[l].x);
+            nvar[l] = (T)acc_zw[l].y;
+            wv[l] = wc[l] = wsum[l];
+        }
+    } else {
+#pragma unroll
+        for (int i = -2; i <= 2; i++) {
+            int qx = px + STRIDE * i;
+            if (qx < 0 || qx >= W)
+                continue;
+#pragma unroll
+            for (int j = -2; j <= 2; j++) {
+                int qy = py + STRIDE * j;
+                if (qy < 0 || qy >= R)
+                    continue;
+                const int lx = cx + STRIDE * i, ly = cy + j;
+                T h = hk[i < 0 ? -i : i] * hk[j < 0 ? -j : j];
+                const V4<T> nd_q = s_nd[ly][lx];
+                T w_z, w_n;
+                geo_weights(nd_p.w, nd_q.w, grad, cvt<T>((float)(STRIDE * i)), cvt<T>((float)(STRIDE * j)), xyz(nd_p), xyz(nd_q), w_z, w_n);
+                T wzn = w_z * w_n;
+                const V2<T> il_q = s_il[ly][lx];
+                const T iq[2] = {il_q.x, il_q.y};
+#pragma unroll
+                for (int l = 0; l < 2; l++) {
+                    float num = -(float)tabs(illum_p[l] - iq[l]);
+#ifdef LPRT_EXACT_SVGF_MATH
+                    T w_l = cvt<T>(svgf_exp(svgf_div(num, den_l[l])));
+#else
+                    T w_l = cvt<T>(__builtin_amdgcn_exp2f(num * k_l[l]));
+#endif
+                    T hw = h * (wzn * w_l);
+                    if (tfinite(hw)) {
+                        const V4<T> cq = LDS_COLOR ? (l == 0 ? s_c0[ly][lx] : s_c1[ly][lx]) : in[l][(uint32_t)(qy * W + qx)];
+                        if (tfinite(cq.w)) {
+                            nvar[l] = nvar[l] + hw * hw * cq.w;
+                            wv[l] = wv[l] + hw;
+                        }
+                        if (tfinite(cq.x) && tfinite(cq.y) && tfinite(cq.z)) {
+                            ncol[l] = ncol[l] + hw * xyz(cq);
+                            wc[l] = wc[l] + hw;
+                        }
                     }
                 }
             }
@@ -512,12 +579,13 @@ template <typename T> void launch_wavelet(hipStream_t st, const FrameDev<T> &fb,
     const uint32_t lattice_rows = (fb.win.rows() + stride - 1) / stride; // per phase (upper bound)
     const dim3 g((fb.win.W + WV_BX - 1) / WV_BX, stride * ((lattice_rows + WV_BY - 1) / WV_BY)), b(256);
     const SvgfLobe<T> &a = fb.lobe[0], &w = fb.lobe[1];
+    const int at = std::getenv("LPRT_SVGF_ALWAYS_TEST") != nullptr;
     switch (level) {
-    case 0: hipLaunchKernelGGL((k_wavelet<T, 1>), g, b, 0, st, fb, a.cv_c, a.cv_b, w.cv_c, w.cv_b, a.var_c, a.var_b, w.var_c, w.var_b); break;
-    case 1: hipLaunchKernelGGL((k_wavelet<T, 2>), g, b, 0, st, fb, a.cv_b, a.cv_a, w.cv_b, w.cv_a, a.var_b, a.var_a, w.var_b, w.var_a); break;
-    case 2: hipLaunchKernelGGL((k_wavelet<T, 4>), g, b, 0, st, fb, a.cv_a, a.cv_c, w.cv_a, w.cv_c, a.var_a, a.var_c, w.var_a, w.var_c); break;
-    case 3: hipLaunchKernelGGL((k_wavelet<T, 8>), g, b, 0, st, fb, a.cv_c, a.cv_a, w.cv_c, w.cv_a, a.var_c, a.var_a, w.var_c, w.var_a); break;
-    default: hipLaunchKernelGGL((k_wavelet<T, 16>), g, b, 0, st, fb, a.cv_a, a.cv_c, w.cv_a, w.cv_c, a.var_a, a.var_c, w.var_a, w.var_c); break;
+    case 0: hipLaunchKernelGGL((k_wavelet<T, 1>), g, b, 0, st, fb, a.cv_c, a.cv_b, w.cv_c, w.cv_b, a.var_c, a.var_b, w.var_c, w.var_b, at); break;
+    case 1: hipLaunchKernelGGL((k_wavelet<T, 2>), g, b, 0, st, fb, a.cv_b, a.cv_a, w.cv_b, w.cv_a, a.var_b, a.var_a, w.var_b, w.var_a, at); break;
+    case 2: hipLaunchKernelGGL((k_wavelet<T, 4>), g, b, 0, st, fb, a.cv_a, a.cv_c, w.cv_a, w.cv_c, a.var_a, a.var_c, w.var_a, w.var_c, at); break;
+    case 3: hipLaunchKernelGGL((k_wavelet<T, 8>), g, b, 0, st, fb, a.cv_c, a.cv_a, w.cv_c, w.cv_a, a.var_c, a.var_a, w.var_c, w.var_a, at); break;
+    default: hipLaunchKernelGGL((k_wavelet<T, 16>), g, b, 0, st, fb, a.cv_a, a.cv_c, w.cv_a, w.cv_c, a.var_a, a.var_c, w.var_a, w.var_c, at); break;
     }
 }
 template <typename T>
