@@ -383,18 +383,11 @@ template <typename T> struct Impl : CtxBase {
         if (!seeds_a.empty() || !seeds_b.empty()) {
             d_rng_planes.reserve(sizeof(uint32_t) * (b_planes_at + 5 * (size_t)s_npix * seeds_b.size()));
             stage(LPRT_STAGE_RNG, [&] {
-                uint32_t *planes = d_rng_planes.as<uint32_t>();
-                if (whole) {
-                    std::vector<uint64_t> all(seeds_a);
-                    all.insert(all.end(), seeds_b.begin(), seeds_b.end());
-                    rng.generate(stream, all.data(), (uint32_t)all.size(), total_px, first_px, npix, planes, seed_d.data());
-                } else {
-                    if (!seeds_a.empty())
-                        rng.generate(stream, seeds_a.data(), (uint32_t)seeds_a.size(), total_px, first_px, npix, planes, seed_d.data());
-                    if (!seeds_b.empty())
-                        rng.generate(stream, seeds_b.data(), (uint32_t)seeds_b.size(), total_px, s_first_px, s_npix, planes + b_planes_at,
-                                     seed_d.data() + seeds_a.size());
-                }
+                // one batch: seed A over the window, the B seeds over the sample rows (the same range when `whole`)
+                std::vector<uint64_t> all(seeds_a);
+                all.insert(all.end(), seeds_b.begin(), seeds_b.end());
+                rng.generate(stream, all.data(), (uint32_t)all.size(), (uint32_t)seeds_a.size(), total_px, first_px, npix, s_first_px, s_npix,
+                             d_rng_planes.as<uint32_t>(), seed_d.data());
             });
         }
         jitter_d = first ? 0u : seed_d[0];

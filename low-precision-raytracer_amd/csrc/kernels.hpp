@@ -54,6 +54,8 @@ struct RngStore {
     // xorwow states of curand_init(seed_i, n, 0) for global pixels n in [first, first + count) -> planes[i][5][count], d_out[i]
     void generate(hipStream_t st, const uint64_t *seeds, uint32_t n_seeds, uint32_t total_pixels, uint32_t first, uint32_t count, uint32_t *planes,
                   uint32_t *d_out);
+    void generate(hipStream_t st, const uint64_t *seeds, uint32_t n_seeds, uint32_t n_head, uint32_t total_pixels, uint32_t first, uint32_t count,
+                  uint32_t first2, uint32_t count2, uint32_t *planes, uint32_t *d_out);
 };
 
 } // namespace lprt

@@ -213,13 +213,23 @@ static inline void seed_state(uint64_t seed, uint32_t v[5], uint32_t &d) { // cu
 // seed of the batch; d_out[i] = d(seed i).  No host synchronisation.
 void RngStore::generate(hipStream_t st, const uint64_t *seeds, uint32_t n_seeds, uint32_t total_pixels, uint32_t first, uint32_t count,
                         uint32_t *planes, uint32_t *d_out) {
+    generate(st, seeds, n_seeds, n_seeds, total_pixels, first, count, first, count, planes, d_out);
+}
+
+// Two pixel ranges in one batch: the first n_head seeds cover [first, first + count), the others [first2, first2 + count2)
+// (sharded frames: the TAA jitter seed covers a rank's whole window, the per-sample seeds only the rows it traces).  The
+// upper expansion levels do not depend on the range and run once for all seeds; planes = the head seeds' planes
+// ([5][count] each), then the others' ([5][count2] each).
+void RngStore::generate(hipStream_t st, const uint64_t *seeds, uint32_t n_seeds, uint32_t n_head, uint32_t total_pixels, uint32_t first,
+                        uint32_t count, uint32_t first2, uint32_t count2, uint32_t *planes, uint32_t *d_out) {
     const Tables &t = tables();
     const uint32_t n1 = (total_pixels + 63) / 64, n2 = (n1 + 63) / 64, n3 = (n2 + 63) / 64;
     if (n3 > 64)
         throw std::string("frame too large for the RNG expansion (more than 2^24 pixels)");
     const XorMat *mats = d_mats.as<XorMat>();
     const uint32_t w2_stride = n3 * 64, w1_stride = n2 * 64;
-    const uint32_t s_begin = first / 64, s_end = (first + count + 63) / 64;
+    if (first == first2 && count == count2)
+        n_head = n_seeds; // one range: one last-level launch per batch
     uint32_t done = 0;
     while (done < n_seeds) {
         const uint32_t batch = n3 <= 16 ? std::min<uint32_t>(RNG_MAX_BATCH, n_seeds - done) : 1;
@@ -240,7 +250,6 @@ void RngStore::generate(hipStream_t st, const uint64_t *seeds, uint32_t n_seeds,
                 h_apply(t.m_top, v, v);
             }
         }
-        uint32_t *out = planes + (size_t)done * 5 * count;
         if (n3 <= 16)
             hipLaunchKernelGGL(k_rng_expand<2>, dim3((n3 + RNG_S - 1) / RNG_S, 4, batch), dim3(256), 0, st, mats + 128, (const uint32_t *)nullptr, topb, top1, n3,
                                0u, 0u, d_w2.as<uint32_t>(), 0u, w2_stride, w2_stride, 5 * w2_stride);
@@ -249,9 +258,20 @@ void RngStore::generate(hipStream_t st, const uint64_t *seeds, uint32_t n_seeds,
                                0u, 0u, d_w2.as<uint32_t>(), 0u, w2_stride, w2_stride, 5 * w2_stride);
         hipLaunchKernelGGL(k_rng_expand<0>, dim3((n2 + RNG_S - 1) / RNG_S, 4, batch), dim3(256), 0, st, mats + 64, d_w2.as<uint32_t>(), topb, top1, n2, w2_stride,
                            5 * w2_stride, d_w1.as<uint32_t>(), 0u, w1_stride, w1_stride, 5 * w1_stride);
-        // last level only for the L1 vectors that cover [first, first + count)
-        hipLaunchKernelGGL(k_rng_expand<0>, dim3((s_end - s_begin + RNG_S - 1) / RNG_S, 4, batch), dim3(256), 0, st, mats, d_w1.as<uint32_t>() + s_begin, topb,
-                           top1, s_end - s_begin, w1_stride, 5 * w1_stride, out, first - s_begin * 64, count, count, 5 * count);
+        // last level only for the L1 vectors that cover a seed's pixel range: one launch per range present in the batch
+        for (int part = 0; part < 2; part++) {
+            const uint32_t z0 = part == 0 ? done : std::max(done, n_head), z1 = part == 0 ? std::min(done + batch, n_head) : done + batch;
+            if (z0 >= z1)
+                continue;
+            const uint32_t f = part == 0 ? first : first2, c = part == 0 ? count : count2;
+            if (c == 0)
+                continue;
+            const uint32_t s_begin = f / 64, s_end = (f + c + 63) / 64;
+            uint32_t *out = part == 0 ? planes + (size_t)z0 * 5 * count : planes + (size_t)n_head * 5 * count + (size_t)(z0 - n_head) * 5 * count2;
+            hipLaunchKernelGGL(k_rng_expand<0>, dim3((s_end - s_begin + RNG_S - 1) / RNG_S, 4, z1 - z0), dim3(256), 0, st, mats,
+                               d_w1.as<uint32_t>() + (size_t)(z0 - done) * 5 * w1_stride + s_begin, topb, top1, s_end - s_begin, w1_stride, 5 * w1_stride, out,
+                               f - s_begin * 64, c, c, 5 * c);
+        }
         done += batch;
     }
     LPRT_HIP(hipGetLastError());
