@@ -194,31 +194,55 @@ __global__ void k_radix_hist(const unsigned long long *keys, uint32_t n, int shi
     hist[threadIdx.x * n_blocks + blockIdx.x] = h[threadIdx.x]; // digit-major: a global scan yields scatter bases
 }
 
-// exclusive scan of `total` counters by one workgroup (total = 256 * n_blocks, small)
-__global__ void k_exclusive_scan(uint32_t *data, uint32_t total) {
-    __shared__ uint32_t part[RS_THREADS];
-    __shared__ uint32_t carry;
-    if (threadIdx.x == 0)
-        carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < total; base += RS_THREADS) {
-        uint32_t i = base + threadIdx.x;
-        uint32_t v = i < total ? data[i] : 0;
-        part[threadIdx.x] = v;
-        __syncthreads();
-        for (int off = 1; off < RS_THREADS; off <<= 1) { // Hillis-Steele inclusive scan
-            uint32_t add = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0;
-            __syncthreads();
-            part[threadIdx.x] += add;
-            __syncthreads();
+// exclusive scan of `total` counters (256 * n_blocks, a multiple of 4) by one workgroup of 1024 threads: tiles of 16 K
+// counters, 16 consecutive ones per thread (four 16-B loads), wave scan by shuffles, the 16 wave totals through LDS.
+// 32 K counters (the 262 k-triangle atrium) are two tiles; the former one-element-per-thread Hillis-Steele loop took
+// 136 us there, two thirds of the whole BLAS build.
+constexpr int SCAN_THREADS = 1024, SCAN_PER_THREAD = 16;
+__global__ void __launch_bounds__(SCAN_THREADS) k_exclusive_scan(uint32_t *data, uint32_t total) {
+    __shared__ uint32_t wsum[SCAN_THREADS / 64];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < total; base += SCAN_THREADS * SCAN_PER_THREAD) {
+        const uint32_t i0 = base + SCAN_PER_THREAD * threadIdx.x;
+        uint32_t v[SCAN_PER_THREAD];
+#pragma unroll
+        for (int j = 0; j < SCAN_PER_THREAD; j += 4) {
+            uint4 q = make_uint4(0u, 0u, 0u, 0u);
+            if (i0 + j < total) // total % 4 == 0 and i0 + j % 4 == 0: a whole quad or nothing
+                q = *reinterpret_cast<const uint4 *>(data + i0 + j);
+            v[j] = q.x, v[j + 1] = q.y, v[j + 2] = q.z, v[j + 3] = q.w;
         }
-        uint32_t incl = part[threadIdx.x];
-        if (i < total)
-            data[i] = carry + incl - v;
+        uint32_t sum = 0;
+#pragma unroll
+        for (int j = 0; j < SCAN_PER_THREAD; j++) { // v[j] <- exclusive prefix within the thread
+            const uint32_t x = v[j];
+            v[j] = sum;
+            sum += x;
+        }
+        uint32_t incl = sum;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off);
+            if (lane >= (uint32_t)off)
+                incl += up;
+        }
+        if (lane == 63)
+            wsum[wave] = incl;
         __syncthreads();
-        if (threadIdx.x == RS_THREADS - 1)
-            carry += incl;
-        __syncthreads();
+        uint32_t before = 0, tile = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < SCAN_THREADS / 64; w++) {
+            const uint32_t x = wsum[w];
+            before += w < wave ? x : 0u;
+            tile += x;
+        }
+        const uint32_t excl = carry + before + incl - sum;
+#pragma unroll
+        for (int j = 0; j < SCAN_PER_THREAD; j += 4)
+            if (i0 + j < total)
+                *reinterpret_cast<uint4 *>(data + i0 + j) = make_uint4(excl + v[j], excl + v[j + 1], excl + v[j + 2], excl + v[j + 3]);
+        carry += tile;
+        __syncthreads(); // wsum is rewritten by the next tile
     }
 }
 
@@ -858,7 +882,7 @@ template <typename T> void GeometryStore<T>::radix_sort(hipStream_t st, const st
     for (int shift : shifts) {
         hipLaunchKernelGGL(k_radix_hist, dim3(n_blocks), dim3(RS_THREADS), 0, st, d_keys[cur].as<unsigned long long>(), n_tris, shift,
                            d_hist.as<uint32_t>(), n_blocks);
-        hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(RS_THREADS), 0, st, d_hist.as<uint32_t>(), 256 * n_blocks);
+        hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(SCAN_THREADS), 0, st, d_hist.as<uint32_t>(), 256 * n_blocks);
         hipLaunchKernelGGL(k_radix_scatter, dim3(n_blocks), dim3(RS_THREADS), 0, st, d_keys[cur].as<unsigned long long>(),
                            d_vals[cur].as<uint32_t>(), d_keys[cur ^ 1].as<unsigned long long>(), d_vals[cur ^ 1].as<uint32_t>(), n_tris, shift,
                            d_hist.as<uint32_t>(), n_blocks);
