@@ -83,8 +83,10 @@ template <typename T> __global__ void __launch_bounds__(256) k_depth_gradient(Fr
     const uint32_t W = fb.win.W, x = p % W, ly = p / W;
     const T dp = fb.g_normal_depth[p].w;
     V2<T> g;
-    g.x = (x == 0) ? fb.g_normal_depth[p + 1].w - dp : dp - fb.g_normal_depth[p - 1].w;
-    g.y = (ly == 0) ? fb.g_normal_depth[p + W].w - dp : dp - fb.g_normal_depth[p - W].w;
+    // (no neighbour to difference against in a one-pixel-wide / one-row window: gradient 0 instead of the reference's read
+    // past the surface)
+    g.x = (x == 0) ? (W > 1 ? fb.g_normal_depth[p + 1].w - dp : (T)0) : dp - fb.g_normal_depth[p - 1].w;
+    g.y = (ly == 0) ? (fb.win.rows() > 1 ? fb.g_normal_depth[p + W].w - dp : (T)0) : dp - fb.g_normal_depth[p - W].w;
     fb.depth_gradient[p] = g;
 }
 

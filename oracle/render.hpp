@@ -1417,12 +1417,14 @@ template <typename T> class Renderer {
                 T dp = nd[3];
                 s.depth[tid] = dp;
                 Vec2<T> g;
+                // (a one-pixel-wide or one-pixel-high image has no neighbour to difference against: the reference reads past
+                // the surface there; here the gradient is 0)
                 if (x == 0)
-                    g[0] = g_normal_depth[tid + 1][3] - dp;
+                    g[0] = W > 1 ? T(g_normal_depth[tid + 1][3] - dp) : T(0);
                 else
                     g[0] = dp - g_normal_depth[tid - 1][3];
                 if (y == 0)
-                    g[1] = g_normal_depth[tid + W][3] - dp;
+                    g[1] = H > 1 ? T(g_normal_depth[tid + W][3] - dp) : T(0);
                 else
                     g[1] = dp - g_normal_depth[tid - W][3];
                 s.depth_gradient[tid] = g;
