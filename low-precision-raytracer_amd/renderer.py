@@ -68,6 +68,15 @@ def load_library():
     """dlopen the HIP library and bind every entry point; raises LprtError when it is not built."""
     global _LIB
     if _LIB is None:
+        # This harness shares its process with PyTorch (device tensors, streams, torch.distributed), and PyTorch's wheel
+        # carries its own libamdhip64.so / libhsa-runtime64.so with the same SONAMEs as /opt/rocm's.  Whichever HIP runtime
+        # is loaded first serves liblprt_hip.so; loading ours first and torch later would leave TWO HIP and TWO HSA runtimes
+        # driving one GPU from one process.  So torch goes first wherever it is installed (a C/C++ host links the system
+        # runtime alone and is not affected).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         path = library_path()
         if not os.path.exists(path):
             raise LprtError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
