@@ -29,6 +29,10 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
+        try:  # PyTorch bundles a libgomp with the system SONAME: let it load first so the process keeps ONE OpenMP runtime
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(build())
         L.orc_create.restype = C.c_void_p
         L.orc_create.argtypes = [C.c_int, C.c_uint32, C.c_uint32]
