@@ -201,7 +201,10 @@ __global__ void __launch_bounds__(256) k_temporal_color(FrameDev<T> fb, T color_
 
 // geometric part of a tap's weight, shared by both lobes: h * w_z * w_n is NOT pre-multiplied because the
 // reference multiplies w_z * w_n (* w_l) first and h last
-template <typename T> LPRT_DEV void geo_weights(T depth_p, T depth_q, V2<T> grad, T dx, T dy, V3<T> n_p, V3<T> n_q, T &w_z, T &w_n) {
+// w_n of a neighbour whose normal equals the centre's bit for bit is pow(max(0, dot(n_p, n_p)), 128): one value per pixel
+template <typename T> LPRT_DEV T normal_weight(V3<T> n_p, V3<T> n_q) { return cvt<T>(svgf_pow128((float)tmax((T)0, dot(n_p, n_q)))); }
+template <typename T>
+LPRT_DEV void geo_weights(T depth_p, T depth_q, V2<T> grad, T dx, T dy, V3<T> n_p, V3<T> n_q, T &w_z, T &w_n, T w_nn, bool flat_ok) {
     // exp(-abs(dz) / (SIGMA_Z * abs(dot(grad, dp) + EPS))): the unary minus makes the quotient a float.
     // Traced G-buffers carry depth 1 on every covered pixel (Q11), so dz is 0 for all taps of nearly every wave: then
     // the quotient is -0 (the denominator is never 0: dot(grad, dp) is an integer multiple of the stride, EPS is not)
@@ -212,7 +215,13 @@ template <typename T> LPRT_DEV void geo_weights(T depth_p, T depth_q, V2<T> grad
         float den = (float)((T)1 * tabs(dot(grad, V2<T>{dx, dy}) + SvgfConst<T>::eps()));
         w_z = cvt<T>(svgf_exp(svgf_div(num, den)));
     }
-    w_n = cvt<T>(svgf_pow128((float)tmax((T)0, dot(n_p, n_q))));
+    // Flat surfaces: every lane's neighbour carries the centre's normal, dot(n_p, n_q) IS dot(n_p, n_p), and the wave skips
+    // the dot product and the seven squarings for the per-pixel value the caller computed once.
+    const bool same = n_q.x == n_p.x && n_q.y == n_p.y && n_q.z == n_p.z;
+    if (flat_ok && !__builtin_amdgcn_ballot_w64(!same))
+        w_n = w_nn;
+    else
+        w_n = normal_weight(n_p, n_q);
 }
 
 // ---- temporal_accumulation_moments (cuda.hpp:1245-1337), both lobes ---------------------------------------------------
@@ -244,7 +253,7 @@ __global__ void __launch_bounds__(256) k_moments(FrameDev<T> fb, T moments_w) {
                 T h = hk[i < 0 ? -i : i] * hk[j < 0 ? -j : j];
                 const V4<T> nd_q = fb.g_normal_depth[q];
                 T w_z, w_n;
-                geo_weights(nd_p.w, nd_q.w, grad, cvt<T>((float)i), cvt<T>((float)j), xyz(nd_p), xyz(nd_q), w_z, w_n);
+                geo_weights(nd_p.w, nd_q.w, grad, cvt<T>((float)i), cvt<T>((float)j), xyz(nd_p), xyz(nd_q), w_z, w_n, zero, false);
                 T hw = h * (w_z * w_n);
                 if (tfinite(hw)) {
 #pragma unroll
@@ -380,6 +389,9 @@ __global__ void __launch_bounds__(256) k_wavelet(FrameDev<T> fb, const V4<T> *in
 #endif
     // 2. 5x5 a-trous taps, x outer / y inner as in the reference
     const V4<T> nd_p = s_nd[cy][cx];
+    // (half only: in single precision the skip measured 3 % slower, 0.650 vs 0.628 ms -- that kernel is not bound by its VALU count)
+    const bool FLAT = sizeof(T) == 2 && !always_test;
+    const T w_nn = normal_weight(xyz(nd_p), xyz(nd_p));
     const V2<T> grad = fb.depth_gradient[p];
     const V2<T> il_p = s_il[cy][cx];
     const T illum_p[2] = {il_p.x, il_p.y};
@@ -403,7 +415,7 @@ __global__ void __launch_bounds__(256) k_wavelet(FrameDev<T> fb, const V4<T> *in
                 T h = hk[i < 0 ? -i : i] * hk[j < 0 ? -j : j];
                 const V4<T> nd_q = s_nd[ly][lx];
                 T w_z, w_n;
-                geo_weights(nd_p.w, nd_q.w, grad, cvt<T>((float)(STRIDE * i)), cvt<T>((float)(STRIDE * j)), xyz(nd_p), xyz(nd_q), w_z, w_n);
+                geo_weights(nd_p.w, nd_q.w, grad, cvt<T>((float)(STRIDE * i)), cvt<T>((float)(STRIDE * j)), xyz(nd_p), xyz(nd_q), w_z, w_n, w_nn, FLAT);
                 T wzn = w_z * w_n;
                 const V2<T> il_q = s_il[ly][lx];
                 const T iq[2] = {il_q.x, il_q.y};
@@ -447,7 +459,7 @@ __global__ void __launch_bounds__(256) k_wavelet(FrameDev<T> fb, const V4<T> *in
                 T h = hk[i < 0 ? -i : i] * hk[j < 0 ? -j : j];
                 const V4<T> nd_q = s_nd[ly][lx];
                 T w_z, w_n;
-                geo_weights(nd_p.w, nd_q.w, grad, cvt<T>((float)(STRIDE * i)), cvt<T>((float)(STRIDE * j)), xyz(nd_p), xyz(nd_q), w_z, w_n);
+                geo_weights(nd_p.w, nd_q.w, grad, cvt<T>((float)(STRIDE * i)), cvt<T>((float)(STRIDE * j)), xyz(nd_p), xyz(nd_q), w_z, w_n, w_nn, FLAT);
                 T wzn = w_z * w_n;
                 const V2<T> il_q = s_il[ly][lx];
                 const T iq[2] = {il_q.x, il_q.y};
