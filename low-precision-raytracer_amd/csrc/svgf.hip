@@ -303,10 +303,18 @@ __global__ void __launch_bounds__(256) k_moments(FrameDev<T> fb, T moments_w) {
 #ifndef LPRT_WV_LDS_BELOW
 #define LPRT_WV_LDS_BELOW 8
 #endif
-constexpr int WV_BX = 64, WV_BY = 4;
+constexpr int WV_BX = 64;
+#ifndef LPRT_WV_BY32
+#define LPRT_WV_BY32 8
+#endif
+// rows of lattice points per workgroup: single precision stages 56 B per texel and is bound by how many waves its LDS tiles
+// leave room for -- 8 rows (512 threads) amortise the 4 halo rows better than 4 (6 instead of 4-5 waves per SIMD at strides
+// 1 and 2); half precision has room to spare and keeps 4
+template <typename T> struct WvRows { static constexpr int value = sizeof(T) == 4 ? LPRT_WV_BY32 : 4; };
 template <typename T, int STRIDE>
-__global__ void __launch_bounds__(256) k_wavelet(FrameDev<T> fb, const V4<T> *in0, V4<T> *out0, const V4<T> *in1, V4<T> *out1, const T *vin0, T *vout0,
+__global__ void __launch_bounds__(WV_BX * WvRows<T>::value) k_wavelet(FrameDev<T> fb, const V4<T> *in0, V4<T> *out0, const V4<T> *in1, V4<T> *out1, const T *vin0, T *vout0,
                                                  const T *vin1, T *vout1, int always_test) {
+    constexpr int WV_BY = WvRows<T>::value, WV_THREADS = WV_BX * WV_BY;
     constexpr int TW = WV_BX + 4 * STRIDE, TH = WV_BY + 4;
     // fp32 at strides 8 and 16: four staged planes (56 B per texel) leave room for only 3 / 2 workgroups per CU, and
     // the kernel is latency-bound; there the colour planes are read straight from L1/L2 (rows are still contiguous
@@ -328,7 +336,7 @@ __global__ void __launch_bounds__(256) k_wavelet(FrameDev<T> fb, const V4<T> *in
         __syncthreads();
     }
     bool bad = false;
-    for (int e = (int)threadIdx.x; e < TW * TH; e += 256) {
+    for (int e = (int)threadIdx.x; e < TW * TH; e += WV_THREADS) {
         const int lx = e % TW, ly = e / TW;
         const int gx = x0 + lx, gy = oy + STRIDE * (r0 + ly);
         if (gx >= 0 && gx < W && gy >= 0 && gy < R) {
@@ -591,7 +599,8 @@ template <typename T> void launch_moments(hipStream_t st, const FrameDev<T> &fb,
 template <typename T> void launch_wavelet(hipStream_t st, const FrameDev<T> &fb, int level) {
     const uint32_t stride = 1u << level;
     const uint32_t lattice_rows = (fb.win.rows() + stride - 1) / stride; // per phase (upper bound)
-    const dim3 g((fb.win.W + WV_BX - 1) / WV_BX, stride * ((lattice_rows + WV_BY - 1) / WV_BY)), b(256);
+    constexpr int WV_BY = WvRows<T>::value;
+    const dim3 g((fb.win.W + WV_BX - 1) / WV_BX, stride * ((lattice_rows + WV_BY - 1) / WV_BY)), b(WV_BX * WV_BY);
     const SvgfLobe<T> &a = fb.lobe[0], &w = fb.lobe[1];
     const int at = std::getenv("LPRT_SVGF_ALWAYS_TEST") != nullptr;
     switch (level) {
