@@ -304,13 +304,19 @@ __global__ void __launch_bounds__(256) k_moments(FrameDev<T> fb, T moments_w) {
 #define LPRT_WV_LDS_BELOW 8
 #endif
 constexpr int WV_BX = 64;
+#ifndef LPRT_WV_FAST32
+#define LPRT_WV_FAST32 0 // the one-test taps and the flat-normal skip in single precision: measured slower, see below
+#endif
 #ifndef LPRT_WV_BY32
 #define LPRT_WV_BY32 8
 #endif
 // rows of lattice points per workgroup: single precision stages 56 B per texel and is bound by how many waves its LDS tiles
 // leave room for -- 8 rows (512 threads) amortise the 4 halo rows better than 4 (6 instead of 4-5 waves per SIMD at strides
 // 1 and 2); half precision has room to spare and keeps 4
-template <typename T> struct WvRows { static constexpr int value = sizeof(T) == 4 ? LPRT_WV_BY32 : 4; };
+#ifndef LPRT_WV_BY16
+#define LPRT_WV_BY16 4
+#endif
+template <typename T> struct WvRows { static constexpr int value = sizeof(T) == 4 ? LPRT_WV_BY32 : LPRT_WV_BY16; };
 template <typename T, int STRIDE>
 __global__ void __launch_bounds__(WV_BX * WvRows<T>::value) k_wavelet(FrameDev<T> fb, const V4<T> *in0, V4<T> *out0, const V4<T> *in1, V4<T> *out1, const T *vin0, T *vout0,
                                                  const T *vin1, T *vout1, int always_test) {
@@ -329,7 +335,7 @@ __global__ void __launch_bounds__(WV_BX * WvRows<T>::value) k_wavelet(FrameDev<T
     const int x0 = (int)blockIdx.x * WV_BX - 2 * STRIDE; // image x of tile column 0
     const int r0 = WV_BY * by - 2;                        // lattice row of tile row 0
     // in single precision the one-test form measured 2 % slower than the tested one (0.649 vs 0.633 ms): half only
-    constexpr bool FAST = LDS_COLOR && sizeof(T) == 2;
+    constexpr bool FAST = LDS_COLOR && (sizeof(T) == 2 || LPRT_WV_FAST32);
     if (FAST) {
         if (threadIdx.x == 0)
             s_nonfinite = 0u;
@@ -398,7 +404,7 @@ __global__ void __launch_bounds__(WV_BX * WvRows<T>::value) k_wavelet(FrameDev<T
     // 2. 5x5 a-trous taps, x outer / y inner as in the reference
     const V4<T> nd_p = s_nd[cy][cx];
     // (half only: in single precision the skip measured 3 % slower, 0.650 vs 0.628 ms -- that kernel is not bound by its VALU count)
-    const bool FLAT = sizeof(T) == 2 && !always_test;
+    const bool FLAT = (sizeof(T) == 2 || LPRT_WV_FAST32) && !always_test;
     const T w_nn = normal_weight(xyz(nd_p), xyz(nd_p));
     const V2<T> grad = fb.depth_gradient[p];
     const V2<T> il_p = s_il[cy][cx];
