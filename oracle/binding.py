@@ -99,7 +99,9 @@ class Oracle:
         self.h = self.L.orc_create(precision, width, height)
         if not self.h:
             raise RuntimeError("orc_create failed")
-        self.L.orc_set_threads(self.h, threads or (os.cpu_count() or 1))
+        # default: the CPUs this process may run on, at most 32 (a GPU box shows 256 logical CPUs but grants a share of them:
+        # 255 spinning OpenMP workers only get in each other's way)
+        self.L.orc_set_threads(self.h, threads or max(1, min(len(os.sched_getaffinity(0)), 32)))
 
     def close(self):
         if self.h:
