@@ -193,7 +193,14 @@ typedef enum {
     LPRT_BUF_RAW_GI_WHITE = 15,    /* [rows][W][3] */
     LPRT_BUF_RAW_COLOR = 16,       /* [rows][W][3] color_inprogress before add_denoised_color */
     LPRT_BUF_GI_DIRECTION = 17,    /* [rows][W][4] last sample's GI ray direction (TraceGICommand), w = 1 where a ray was cast */
-    LPRT_BUF_COUNT = 18
+    /* the shadow-ray commands the LAST shade of the frame left (TraceLightCommand, rt/rtrt/cuda.hpp:1014-1032): round 1 of
+     * the last sample with gi_on, round 0 otherwise.  Parity tests replay them through lprt_trace_rays and the oracle to
+     * tell "a ray found something else" apart from "the arithmetic differs".  Whole-window contexts only (no sample rows). */
+    LPRT_BUF_LIGHT_DIR_MAXT = 18,  /* [4 slots][rows][W][4] direction.xyz, maximum_t */
+    LPRT_BUF_LIGHT_MASK = 19,      /* [rows][W][1] bit s set: slot s holds a command */
+    LPRT_BUF_SHADE_POSITION = 20,  /* [rows][W][3] source of round 1's shadow rays (the GI hit); round 0's is G_POSITION */
+    LPRT_BUF_SKIP = 21,            /* [rows][W][2] SkipGeometry of those rays: vao index, inobject_offset */
+    LPRT_BUF_COUNT = 22
 } lprt_buffer_id;
 
 /* Per-kernel GPU time (HIP events on the context's stream) and work counters; one id per kernel family.
@@ -342,7 +349,9 @@ int lprt_enable_stage_timing(lprt_ctx *ctx, int enable);
  * records per launch cost about 4 us of stream time each on this stack, so a measurement that wants the frame rate
  * AND one kernel's duration instruments that kernel only. */
 int lprt_set_stage_timing_mask(lprt_ctx *ctx, uint32_t stage_mask);
-int lprt_get_stage_times(lprt_ctx *ctx, float ms[LPRT_STAGE_COUNT], uint32_t launches[LPRT_STAGE_COUNT]);
+/* ms / launches: arrays of n entries each (either may be NULL); n must equal LPRT_STAGE_COUNT of the library that is
+ * loaded (lprt_get_abi_info), otherwise LPRT_ERR_INVALID and nothing is written. */
+int lprt_get_stage_times(lprt_ctx *ctx, float *ms, uint32_t *launches, uint32_t n);
 int lprt_reset_stage_times(lprt_ctx *ctx);
 
 /* Acceleration-structure read-back for parity tests against the oracle's traversal:
@@ -358,9 +367,48 @@ int lprt_debug_sample_texture(lprt_ctx *ctx, uint32_t handle, const float *uv, u
 
 /* Test hook: xorwow state words v[0..4], d of curand_init(seed, n, 0) for global pixels n in
  * [first, first + count), as the frame kernels receive them; out = [count][6] uint32. */
-int lprt_debug_rng_states(lprt_ctx *ctx, uint64_t seed, uint32_t first, uint32_t count, uint32_t *out);
+int lprt_debug_rng_states(lprt_ctx *ctx, uint64_t seed, uint32_t first, uint32_t count, uint32_t *out,
+                          size_t out_words /* must be 6 * count */);
 
 const char *lprt_version(void);
+
+/* ---- behaviour knobs --------------------------------------------------------------------- */
+
+/* Every A/B switch of the kernels is a per-context option.  The initial values come from the environment ONCE, in
+ * lprt_create (variable named beside each option); nothing reads the environment after that, so a frame's behaviour cannot
+ * change under the caller's feet.  Results never depend on these (the parity tests hold that); speed does. */
+typedef enum {
+    LPRT_OPT_WIDE_WALK = 0,        /* two BLAS levels per traversal step.  -1 (default): any-hit rays when some BLAS tree is
+                                    * >= 6 levels deep; 0: never; 1: any-hit rays always.  lprt_trace_rays follows the same
+                                    * rule for find_any != 0; with 1 its closest-hit batches take the two-level walk too
+                                    * (hit-record parity of that walk).  LPRT_WIDE_WALK */
+    LPRT_OPT_TLAS_MODE = 1,        /* -1 (default): flat scan for <= 32 instances, tree otherwise; 0: tree; 1: flat scan
+                                    * (only honoured for <= 32 instances).  LPRT_TLAS_MODE */
+    LPRT_OPT_AXIS_REJECT = 2,      /* 1 (default): stationary / overflowed-axis box rejections; 0: the reference's plain
+                                    * slab test.  LPRT_NO_AXIS_REJECT (set = 0) */
+    LPRT_OPT_SVGF_ALWAYS_TEST = 3, /* 0 (default); 1: SVGF window sums always take the per-sample finite tests.
+                                    * LPRT_SVGF_ALWAYS_TEST (set = 1) */
+    LPRT_OPT_BLAS_BUILDER = 4,     /* 0 (default): level-by-level median split; 1: one Morton sort.  LPRT_BLAS_BUILDER=morton */
+    LPRT_OPT_BLAS_LOCAL = 5,       /* 1 (default): subtrees of <= 1024 triangles are ordered in LDS; 0: global passes only.
+                                    * LPRT_BLAS_LOCAL */
+    LPRT_OPT_DEBUG_SYNC = 6,       /* 1: synchronise and report after every stage.  LPRT_DEBUG_SYNC (set = 1) */
+    LPRT_OPT_COUNT = 7
+} lprt_option;
+int lprt_set_option(lprt_ctx *ctx, lprt_option option, int value);
+int lprt_get_option(lprt_ctx *ctx, lprt_option option, int *value);
+
+/* Sizes and counts of the LOADED library, for bindings that mirror this header in another language: a binding compares
+ * them with its own mirror at load time, so that an out-array or struct of the wrong size is an error at start-up and
+ * never a stray write.  info_bytes = sizeof(lprt_abi_info) as the caller knows it; the library fills min(info_bytes, its
+ * own size) bytes. */
+typedef struct {
+    uint32_t info_bytes;
+    uint32_t stage_count, buffer_count, option_count;
+    uint32_t sizeof_vertex, sizeof_mesh_vao, sizeof_material, sizeof_object, sizeof_aabb, sizeof_light, sizeof_camera,
+        sizeof_skybox, sizeof_frame_settings, sizeof_ray, sizeof_hit, sizeof_counters;
+    uint32_t rng_state_words; /* uint32 words per pixel written by lprt_debug_rng_states */
+} lprt_abi_info;
+void lprt_get_abi_info(lprt_abi_info *out, uint32_t info_bytes);
 
 #ifdef __cplusplus
 }

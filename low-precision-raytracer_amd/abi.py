@@ -76,9 +76,11 @@ HIST_SAMPLES = 4               # this frame's per-lobe sample means, exchanged b
 PHASE_SAMPLE, PHASE_RESOLVE = 1, 2
 BUF = dict(COLOR_INPROGRESS=0, MUL_GI_COLORED=1, MUL_GI_WHITE=2, INTENSITY0=3, INTENSITY1=4, ALBEDO=5, OUTPUT=6,
            G_POSITION=7, G_NORMAL_DEPTH=8, G_TANGENT=9, G_UV0UV1=10, G_COLOR=11, G_OBJID=12, G_OFFSET=13,
-           RAW_GI_COLORED=14, RAW_GI_WHITE=15, RAW_COLOR=16, GI_DIRECTION=17)
+           RAW_GI_COLORED=14, RAW_GI_WHITE=15, RAW_COLOR=16, GI_DIRECTION=17, LIGHT_DIR_MAXT=18, LIGHT_MASK=19,
+           SHADE_POSITION=20, SKIP=21)
 BUF_CHANNELS = {0: 3, 1: 3, 2: 3, 3: 3, 4: 3, 5: 3, 6: 4, 7: 4, 8: 4, 9: 4, 10: 4, 11: 4, 12: 1, 13: 1, 14: 3, 15: 3,
-                16: 3, 17: 4}
+                16: 3, 17: 4, 18: 4, 19: 1, 20: 3, 21: 2}
+BUF_PLANES = {18: MAX_DIRECT_LIGHT}  # leading dimension of buffers that are [planes][rows][W][channels]
 STAGES = ["build_blas", "build_tlas", "primary", "temporal_map", "rng", "shade1", "trace_di1", "trace_gi", "shade2",
           "trace_di2", "compose", "svgf_gradient", "svgf_temporal", "svgf_moments", "svgf_wavelet", "finalize", "backup"]
 # device kernel behind each stage id (the names rocprofv3 --kernel-trace reports)
@@ -87,6 +89,26 @@ STAGE_KERNELS = {"primary": "k_fill_gbuffer", "temporal_map": "k_temporal_map", 
                  "compose": "k_compose", "svgf_gradient": "k_depth_gradient", "svgf_temporal": "k_temporal_color",
                  "svgf_moments": "k_moments", "svgf_wavelet": "k_wavelet", "finalize": "k_finalize",
                  "backup": "k_copy_last_transform", "build_tlas": "k_build_tlas"}
+
+# lprt_option, in enum order
+OPTIONS = ["wide_walk", "tlas_mode", "axis_reject", "svgf_always_test", "blas_builder", "blas_local", "debug_sync"]
+RNG_STATE_WORDS = 6
+
+
+class AbiInfo(C.Structure):  # lprt_abi_info
+    _fields_ = [(n, u32) for n in ("info_bytes", "stage_count", "buffer_count", "option_count", "sizeof_vertex", "sizeof_mesh_vao",
+                                   "sizeof_material", "sizeof_object", "sizeof_aabb", "sizeof_light", "sizeof_camera", "sizeof_skybox",
+                                   "sizeof_frame_settings", "sizeof_ray", "sizeof_hit", "sizeof_counters", "rng_state_words")]
+
+
+def expected_abi_info():
+    """What this mirror of include/lprt.h believes; renderer.check_abi compares it with the loaded library."""
+    return dict(info_bytes=C.sizeof(AbiInfo), stage_count=len(STAGES), buffer_count=len(BUF), option_count=len(OPTIONS),
+                sizeof_vertex=C.sizeof(Vertex), sizeof_mesh_vao=C.sizeof(MeshVAO), sizeof_material=C.sizeof(Material),
+                sizeof_object=C.sizeof(Object), sizeof_aabb=C.sizeof(AABB), sizeof_light=C.sizeof(Light), sizeof_camera=C.sizeof(Camera),
+                sizeof_skybox=C.sizeof(Skybox), sizeof_frame_settings=C.sizeof(FrameSettings), sizeof_ray=C.sizeof(Ray),
+                sizeof_hit=C.sizeof(Hit), sizeof_counters=C.sizeof(Counters), rng_state_words=RNG_STATE_WORDS)
+
 
 # numpy dtypes with identical layout (for bulk ray/hit arrays)
 import numpy as np
@@ -99,6 +121,7 @@ VERTEX_DTYPE = np.dtype([("position", "<f4", 3), ("normal", "<f4", 3), ("tangent
                          ("uv0", "<f4", 2), ("uv1", "<f4", 2)])
 assert RAY_DTYPE.itemsize == C.sizeof(Ray) and HIT_DTYPE.itemsize == C.sizeof(Hit)
 assert VERTEX_DTYPE.itemsize == C.sizeof(Vertex) == 64
+assert len(BUF) == len(BUF_CHANNELS)
 
 
 def default_settings(spp=1, gi_on=True, svgf=True, seeds=None):

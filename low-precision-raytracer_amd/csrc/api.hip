@@ -4,7 +4,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
+#include <exception>
 #include <memory>
 #include <new>
 #include <string>
@@ -60,7 +62,7 @@ struct CtxBase {
                            const float *, const lprt_skybox *) = 0;
     virtual void trace_rays(const lprt_ray *, uint32_t, int, lprt_hit *) = 0;
     virtual void get_counters(int stage, lprt_counters *) = 0;
-    virtual void rng_states(uint64_t, uint32_t, uint32_t, uint32_t *) = 0;
+    virtual void rng_states(uint64_t, uint32_t, uint32_t, uint32_t *, size_t) = 0;
     void *ext_out = nullptr;
     uint32_t ext_first_row = 0, ext_rows = 0;
     virtual void reset_counters() = 0;
@@ -76,12 +78,34 @@ struct CtxBase {
     // from the contexts that own those rows (LPRT_HIST_SAMPLES) between the two phases
     uint32_t sample_first = 0, sample_rows = 0; // 0 rows: the whole window
     int next_phase = LPRT_PHASE_SAMPLE;
+    // behaviour knobs (lprt_option): initialised from the environment once, in lprt_create; never read from it afterwards
+    int opts[LPRT_OPT_COUNT] = {-1, -1, 1, 0, 0, 1, 0};
+    void options_from_environment() {
+        if (const char *w = std::getenv("LPRT_WIDE_WALK"))
+            opts[LPRT_OPT_WIDE_WALK] = w[0] == '1' ? 1 : 0;
+        if (const char *m = std::getenv("LPRT_TLAS_MODE"))
+            opts[LPRT_OPT_TLAS_MODE] = m[0] == '1' ? 1 : 0;
+        if (std::getenv("LPRT_NO_AXIS_REJECT"))
+            opts[LPRT_OPT_AXIS_REJECT] = 0;
+        if (std::getenv("LPRT_SVGF_ALWAYS_TEST"))
+            opts[LPRT_OPT_SVGF_ALWAYS_TEST] = 1;
+        if (const char *b = std::getenv("LPRT_BLAS_BUILDER"))
+            opts[LPRT_OPT_BLAS_BUILDER] = std::string(b) == "morton" ? 1 : 0;
+        if (const char *l = std::getenv("LPRT_BLAS_LOCAL"))
+            opts[LPRT_OPT_BLAS_LOCAL] = std::string(l) == "0" ? 0 : 1;
+        if (std::getenv("LPRT_DEBUG_SYNC"))
+            opts[LPRT_OPT_DEBUG_SYNC] = 1;
+    }
+    // rows [first_row, first_row + n_rows) inside the window?  (the sum in 64 bits: first_row + n_rows may wrap in 32)
+    bool rows_inside_window(uint32_t first_row, uint32_t n_rows) const {
+        return first_row >= win.row_begin && (uint64_t)first_row + n_rows <= (uint64_t)win.row_end;
+    }
     void set_sample_rows(uint32_t first_row, uint32_t n_rows) {
         if (n_rows == 0) {
             sample_first = sample_rows = 0;
             return;
         }
-        if (first_row < win.row_begin || first_row + n_rows > win.row_end)
+        if (!rows_inside_window(first_row, n_rows))
             throw std::string("sample rows must lie inside this context's row window");
         sample_first = first_row;
         sample_rows = n_rows;
@@ -105,7 +129,7 @@ struct CtxBase {
     // rows [first_row, first_row + n_rows) of the history planes of the given groups <-> one packed device buffer, plane
     // after plane: ONE kernel launch (a plane's rows are contiguous, so each plane is a flat byte range)
     void copy_history_rows(uint32_t groups, uint32_t first_row, uint32_t n_rows, void *packed, bool to_packed) {
-        if (first_row < win.row_begin || first_row + n_rows > win.row_end)
+        if (!rows_inside_window(first_row, n_rows))
             throw std::string("history rows must lie inside this context's row window");
         CopyJobs jobs{};
         size_t off = 0, longest = 0;
@@ -142,8 +166,8 @@ struct CtxBase {
         }
         return e;
     }
-    bool debug_sync = std::getenv("LPRT_DEBUG_SYNC") != nullptr;
     template <typename F> void stage(int id, F &&f) {
+        const bool debug_sync = opts[LPRT_OPT_DEBUG_SYNC] != 0;
         if ((!timer.enabled || !(timer.mask & (1u << id))) && !debug_sync) {
             f();
             return;
@@ -332,6 +356,8 @@ template <typename T> struct Impl : CtxBase {
         sc.sky_exposure = (T)skybox.exposure;
         return sc;
     }
+    // shadow rays walk deep BLAS trees two levels per step (trace.hpp); LPRT_OPT_WIDE_WALK overrides for A/B runs
+    bool wide_anyhit() const { return opts[LPRT_OPT_WIDE_WALK] < 0 ? geo.max_depth >= 6 : opts[LPRT_OPT_WIDE_WALK] != 0; }
     uint32_t jitter_d = 0; // d word of this frame's seed A, drawn in the sample phase, used by the temporal maps
     void render_phase(const lprt_frame_settings &fs, int phase) override {
         if (phase != next_phase)
@@ -349,7 +375,7 @@ template <typename T> struct Impl : CtxBase {
         ensure_last_L2W();
         const uint32_t spp = fs.spp ? fs.spp : 1;
         if (fs.rebuild_blas) {
-            stage(LPRT_STAGE_BUILD_BLAS, [&] { geo.build_blas(stream); });
+            stage(LPRT_STAGE_BUILD_BLAS, [&] { geo.build_blas(stream, opts[LPRT_OPT_BLAS_BUILDER] == 1, opts[LPRT_OPT_BLAS_LOCAL] != 0); });
             objrecs_dirty = true;
             ensure_objrecs();
         }
@@ -365,10 +391,7 @@ template <typename T> struct Impl : CtxBase {
         };
         stage(LPRT_STAGE_PRIMARY, [&] { launch_fill_gbuffer<T>(stream, sc, fb, stage_counters(LPRT_STAGE_PRIMARY)); });
         const bool first = frame_index == 0;
-        // shadow rays walk deep BLAS trees two levels per step (trace.hpp); LPRT_WIDE_WALK=0|1 overrides for A/B runs
-        bool wide_walk = geo.max_depth >= 6;
-        if (const char *w = std::getenv("LPRT_WIDE_WALK"))
-            wide_walk = w[0] == '1';
+        const bool wide_walk = wide_anyhit();
         // every curand_init of this frame: seed A of sample 0 (TAA jitter, frames >= 1) over the window + seed B of each
         // sample (shade #1 with GI) over the sample rows -- one batch when the two row ranges coincide.  shade #2 runs with
         // NO_GI and draws nothing (cuda.hpp:1900-1999).
@@ -426,10 +449,11 @@ template <typename T> struct Impl : CtxBase {
         if (fs.svgf) {
             // svgf_denoise (cuda.hpp:1636-1711), both lobes per launch
             stage(LPRT_STAGE_SVGF_GRADIENT, [&] { launch_depth_gradient<T>(stream, fb); });
-            stage(LPRT_STAGE_SVGF_TEMPORAL, [&] { launch_temporal_color<T>(stream, fb, fs.svgf_color_mix_weight); });
+            const bool always_test = opts[LPRT_OPT_SVGF_ALWAYS_TEST] != 0;
+            stage(LPRT_STAGE_SVGF_TEMPORAL, [&] { launch_temporal_color<T>(stream, fb, fs.svgf_color_mix_weight, always_test); });
             stage(LPRT_STAGE_SVGF_MOMENTS, [&] { launch_moments<T>(stream, fb, fs.svgf_moments_mix_weight); });
             for (int level = 0; level < 5; level++)
-                stage(LPRT_STAGE_SVGF_WAVELET, [&] { launch_wavelet<T>(stream, fb, level); });
+                stage(LPRT_STAGE_SVGF_WAVELET, [&] { launch_wavelet<T>(stream, fb, level, always_test); });
             // moments history for the next frame: swap instead of the reference's (short) memcpy (DEVIATION Q8)
             for (int l = 0; l < 2; l++) {
                 std::swap(fb.lobe[l].miu1_hist, fb.lobe[l].miu1_cur);
@@ -456,10 +480,12 @@ template <typename T> struct Impl : CtxBase {
     }
     void read_buffer(lprt_buffer_id id, float *dst, size_t n_floats) override {
         ensure_frame_buffers();
-        const uint32_t n = win.npix();
+        const uint32_t n_px = win.npix();
+        uint32_t planes = 1;
         int ch = 3;
         const V4<T> *v4 = nullptr;
         const uint32_t *u32 = nullptr;
+        const uint8_t *u8 = nullptr;
         bool rgba8 = false;
         switch (id) {
         case LPRT_BUF_COLOR_INPROGRESS: v4 = fb.color_inprogress; break;
@@ -480,8 +506,15 @@ template <typename T> struct Impl : CtxBase {
         case LPRT_BUF_G_OFFSET: u32 = fb.g_offset; ch = 1; break;
         case LPRT_BUF_OUTPUT: ch = 4; break;
         case LPRT_BUF_GI_DIRECTION: v4 = fb.gi_direction; ch = 4; break;
+        case LPRT_BUF_LIGHT_DIR_MAXT: v4 = fb.lc_dir_maxt; ch = 4; planes = LPRT_MAX_DIRECT_LIGHT; break;
+        case LPRT_BUF_LIGHT_MASK: u8 = fb.lc_mask; ch = 1; break;
+        case LPRT_BUF_SHADE_POSITION: v4 = fb.sc_position; break;
+        case LPRT_BUF_SKIP: u32 = reinterpret_cast<const uint32_t *>(fb.skips); ch = 1; planes = 2; break; // uint2 = two words per pixel
         default: throw std::string("unknown buffer id");
         }
+        if ((id == LPRT_BUF_LIGHT_DIR_MAXT || id == LPRT_BUF_LIGHT_MASK) && sample_rows != 0 && sample_rows != win.rows())
+            throw std::string("light commands are indexed by sample-row pixel: readable in whole-window contexts only");
+        const uint32_t n = n_px * planes;
         if (n_floats != (size_t)n * ch)
             throw std::string("read_buffer: size mismatch (expected rows*W*channels floats)");
         if (id == LPRT_BUF_OUTPUT) {
@@ -490,6 +523,8 @@ template <typename T> struct Impl : CtxBase {
             d_readback.reserve(sizeof(float) * n_floats);
             if (v4)
                 launch_read_v4<T>(stream, v4, d_readback.as<float>(), n, ch);
+            else if (u8)
+                launch_read_u8(stream, u8, d_readback.as<float>(), n);
             else
                 launch_read_u32(stream, u32, d_readback.as<float>(), n, rgba8);
             LPRT_HIP(hipMemcpyAsync(dst, d_readback.ptr, sizeof(float) * n_floats, hipMemcpyDeviceToHost, stream));
@@ -538,7 +573,7 @@ template <typename T> struct Impl : CtxBase {
         }
     }
     void build_blas() override {
-        stage(LPRT_STAGE_BUILD_BLAS, [&] { geo.build_blas(stream); });
+        stage(LPRT_STAGE_BUILD_BLAS, [&] { geo.build_blas(stream, opts[LPRT_OPT_BLAS_BUILDER] == 1, opts[LPRT_OPT_BLAS_LOCAL] != 0); });
         objrecs_dirty = true;
     }
     void ensure_objrecs() {
@@ -611,12 +646,9 @@ template <typename T> struct Impl : CtxBase {
         sc.tlas_depth = tlas.depth;
         sc.n_objects = tlas.n_objects;
         sc.tlas_mode = tlas.n_objects <= 32u ? 1u : 0u;
-        if (const char *m = std::getenv("LPRT_TLAS_MODE")) { // experiment knob: 0 tree, 1 flat scan
-            uint32_t v = (uint32_t)std::atoi(m);
-            if (v == 0u || (v == 1u && tlas.n_objects <= 32u))
-                sc.tlas_mode = v;
-        }
-        sc.axis_reject = std::getenv("LPRT_NO_AXIS_REJECT") ? 0u : 1u; // A/B switch (results must not depend on it)
+        if (opts[LPRT_OPT_TLAS_MODE] == 0 || (opts[LPRT_OPT_TLAS_MODE] == 1 && tlas.n_objects <= 32u)) // experiment knob: 0 tree, 1 flat scan
+            sc.tlas_mode = (uint32_t)opts[LPRT_OPT_TLAS_MODE];
+        sc.axis_reject = opts[LPRT_OPT_AXIS_REJECT] ? 1u : 0u; // A/B switch (results must not depend on it)
         sc.objects = d_objects.template as<ObjConst<T>>();
         sc.blas = geo.d_blas.template as<BlasInfo>();
         sc.blas_roots = geo.d_roots.template as<T>();
@@ -657,7 +689,10 @@ template <typename T> struct Impl : CtxBase {
         d_rays.reserve(sizeof(lprt_ray) * (size_t)n);
         d_hits.reserve(sizeof(lprt_hit) * (size_t)n);
         LPRT_HIP(hipMemcpyAsync(d_rays.ptr, rays, sizeof(lprt_ray) * (size_t)n, hipMemcpyHostToDevice, stream));
-        launch_trace_rays<T>(stream, scene_dev(), d_rays.as<lprt_ray>(), n, find_any != 0, d_hits.as<lprt_hit>(),
+        // the walk the frame kernels would take: any-hit batches follow wide_anyhit(); LPRT_OPT_WIDE_WALK = 1 also sends
+        // closest-hit batches through the two-level walk (parity of that walk at hit-record level)
+        const bool wide = find_any ? wide_anyhit() : opts[LPRT_OPT_WIDE_WALK] == 1;
+        launch_trace_rays<T>(stream, scene_dev(), d_rays.as<lprt_ray>(), n, find_any != 0, wide, d_hits.as<lprt_hit>(),
                              stage_counters(LPRT_STAGE_PRIMARY));
         LPRT_HIP(hipGetLastError());
         LPRT_HIP(hipMemcpyAsync(hits, d_hits.ptr, sizeof(lprt_hit) * (size_t)n, hipMemcpyDeviceToHost, stream));
@@ -690,7 +725,9 @@ template <typename T> struct Impl : CtxBase {
     }
     void reset_counters() override { LPRT_HIP(hipMemsetAsync(d_counters.ptr, 0, sizeof(Counters) * LPRT_STAGE_COUNT, stream)); }
     Counters *stage_counters(int stage) { return counters_enabled ? d_counters.as<Counters>() + stage : nullptr; }
-    void rng_states(uint64_t seed, uint32_t first, uint32_t count, uint32_t *out) override {
+    void rng_states(uint64_t seed, uint32_t first, uint32_t count, uint32_t *out, size_t out_words) override {
+        if (out_words != 6 * (size_t)count)
+            throw std::string("rng_states: the out array must hold 6 words per pixel");
         if (!rng.ready)
             rng.init(stream);
         if ((uint64_t)first + count > (uint64_t)win.W * win.H || count == 0)
@@ -709,6 +746,8 @@ template <typename T> struct Impl : CtxBase {
         }
     }
     void blas_info(uint32_t vao, uint32_t *n_tris, uint32_t *n_nodes, uint32_t *depth) override {
+        if (!n_tris || !n_nodes || !depth)
+            throw std::string("null out pointer");
         if (vao >= geo.n_vaos)
             throw std::string("vao index out of range");
         const BlasInfo &bi = geo.host_blas[vao];
@@ -724,6 +763,8 @@ template <typename T> struct Impl : CtxBase {
             throw std::string("size mismatch");
         if (!n)
             return;
+        if (!order)
+            throw std::string("null out pointer");
         // sorted values are global triangle ids; report primitive-local triangle indices
         LPRT_HIP(hipMemcpyAsync(order, geo.d_vals[geo.sorted_buf].template as<uint32_t>() + bi.tri_base, sizeof(uint32_t) * (size_t)n,
                                 hipMemcpyDeviceToHost, stream));
@@ -741,6 +782,8 @@ template <typename T> struct Impl : CtxBase {
             throw std::string("size mismatch");
         if (!n_nodes)
             return;
+        if (!boxes)
+            throw std::string("null out pointer");
         uint32_t n_inner = (1u << bi.depth) - 1;
         std::vector<InnerNode<T>> inner(n_inner);
         T root[6];
@@ -774,12 +817,32 @@ struct lprt_ctx {
 
 static thread_local std::string g_create_error;
 
+// makes the context's device current for the duration of one call and puts the caller's device back afterwards (a torch
+// process with several devices must not find its current device changed by a call into this library)
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceScope(int device) {
+        if (hipGetDevice(&prev) != hipSuccess)
+            prev = -1;
+        if (prev != device) {
+            (void)hipSetDevice(device);
+            switched = true;
+        }
+    }
+    ~DeviceScope() {
+        if (switched && prev >= 0)
+            (void)hipSetDevice(prev);
+    }
+};
+
+// no exception crosses the C boundary: whatever is thrown becomes a status code + lprt_last_error text
 template <typename F> static int guarded(lprt_ctx *ctx, F &&f) {
     if (!ctx || !ctx->impl)
         return LPRT_ERR_INVALID;
     CtxBase &c = *ctx->impl;
     try {
-        (void)hipSetDevice(c.device);
+        DeviceScope dev(c.device);
         f(c);
         return LPRT_OK;
     } catch (const HipError &e) {
@@ -793,12 +856,42 @@ template <typename F> static int guarded(lprt_ctx *ctx, F &&f) {
     } catch (const std::bad_alloc &) {
         c.error = "host allocation failed";
         return LPRT_ERR_DEVICE;
+    } catch (const std::exception &e) {
+        c.error = std::string("internal error: ") + e.what();
+        return LPRT_ERR_INVALID;
+    } catch (...) {
+        c.error = "internal error: unknown exception";
+        return LPRT_ERR_INVALID;
     }
 }
 
 extern "C" {
 
-const char *lprt_version(void) { return "lprt-hip 0.2 (gfx950)"; }
+const char *lprt_version(void) { return "lprt-hip 0.3 (gfx950)"; }
+
+void lprt_get_abi_info(lprt_abi_info *out, uint32_t info_bytes) {
+    if (!out || info_bytes < sizeof(uint32_t))
+        return;
+    lprt_abi_info me{};
+    me.info_bytes = (uint32_t)sizeof(lprt_abi_info);
+    me.stage_count = LPRT_STAGE_COUNT;
+    me.buffer_count = LPRT_BUF_COUNT;
+    me.option_count = LPRT_OPT_COUNT;
+    me.sizeof_vertex = (uint32_t)sizeof(lprt_vertex);
+    me.sizeof_mesh_vao = (uint32_t)sizeof(lprt_mesh_vao);
+    me.sizeof_material = (uint32_t)sizeof(lprt_material);
+    me.sizeof_object = (uint32_t)sizeof(lprt_object);
+    me.sizeof_aabb = (uint32_t)sizeof(lprt_aabb);
+    me.sizeof_light = (uint32_t)sizeof(lprt_light);
+    me.sizeof_camera = (uint32_t)sizeof(lprt_camera);
+    me.sizeof_skybox = (uint32_t)sizeof(lprt_skybox);
+    me.sizeof_frame_settings = (uint32_t)sizeof(lprt_frame_settings);
+    me.sizeof_ray = (uint32_t)sizeof(lprt_ray);
+    me.sizeof_hit = (uint32_t)sizeof(lprt_hit);
+    me.sizeof_counters = (uint32_t)sizeof(lprt_counters);
+    me.rng_state_words = 6;
+    std::memcpy(out, &me, std::min<size_t>(info_bytes, sizeof(me)));
+}
 
 int lprt_create(lprt_ctx **out, int device, uint32_t width, uint32_t height, uint32_t row_begin, uint32_t row_end,
                 lprt_precision precision) {
@@ -816,7 +909,7 @@ int lprt_create(lprt_ctx **out, int device, uint32_t width, uint32_t height, uin
         return LPRT_ERR_NO_DEVICE;
     }
     try {
-        LPRT_HIP(hipSetDevice(device));
+        DeviceScope dev(device);
         std::unique_ptr<CtxBase> impl;
         if (precision == LPRT_F32)
             impl.reset(new Impl<float>());
@@ -825,6 +918,7 @@ int lprt_create(lprt_ctx **out, int device, uint32_t width, uint32_t height, uin
         impl->device = device;
         impl->precision = precision;
         impl->win = Window{width, height, row_begin, row_end};
+        impl->options_from_environment(); // the only place the environment is read
         LPRT_HIP(hipStreamCreateWithFlags(&impl->stream, hipStreamNonBlocking));
         impl->own_stream = true;
         auto *ctx = new lprt_ctx();
@@ -838,6 +932,12 @@ int lprt_create(lprt_ctx **out, int device, uint32_t width, uint32_t height, uin
     } catch (const std::string &s) {
         g_create_error = s;
         return LPRT_ERR_INVALID;
+    } catch (const std::exception &e) {
+        g_create_error = std::string("internal error: ") + e.what();
+        return LPRT_ERR_DEVICE;
+    } catch (...) {
+        g_create_error = "internal error: unknown exception";
+        return LPRT_ERR_DEVICE;
     }
 }
 
@@ -845,10 +945,13 @@ void lprt_destroy(lprt_ctx *ctx) {
     if (!ctx)
         return;
     if (ctx->impl) {
-        (void)hipSetDevice(ctx->impl->device);
-        if (ctx->impl->stream)
+        DeviceScope dev(ctx->impl->device);
+        // Nothing of this context may be in flight while its memory goes away.  A stream the caller handed over
+        // (lprt_set_stream) is NOT touched here -- the caller may have destroyed it already; the device-wide
+        // synchronisation covers whatever was enqueued on it.
+        if (ctx->impl->own_stream && ctx->impl->stream)
             (void)hipStreamSynchronize(ctx->impl->stream);
-        (void)hipDeviceSynchronize(); // nothing of this context may be in flight on any stream while its memory goes away
+        (void)hipDeviceSynchronize();
         for (auto &p : ctx->impl->timer.pending) {
             (void)hipEventDestroy(p.a);
             (void)hipEventDestroy(p.b);
@@ -1006,11 +1109,28 @@ int lprt_import_history_rows(lprt_ctx *ctx, uint32_t groups, uint32_t first_row,
         c.copy_history_rows(groups, first_row, n_rows, const_cast<void *>(src_device), false);
     });
 }
-int lprt_debug_rng_states(lprt_ctx *ctx, uint64_t seed, uint32_t first, uint32_t count, uint32_t *out) {
+int lprt_debug_rng_states(lprt_ctx *ctx, uint64_t seed, uint32_t first, uint32_t count, uint32_t *out, size_t out_words) {
     return guarded(ctx, [&](CtxBase &c) {
         if (!out)
             throw std::string("null out pointer");
-        c.rng_states(seed, first, count, out);
+        c.rng_states(seed, first, count, out, out_words);
+    });
+}
+int lprt_set_option(lprt_ctx *ctx, lprt_option option, int value) {
+    return guarded(ctx, [&](CtxBase &c) {
+        if ((int)option < 0 || (int)option >= LPRT_OPT_COUNT)
+            throw std::string("unknown option");
+        const bool tri = option == LPRT_OPT_WIDE_WALK || option == LPRT_OPT_TLAS_MODE; // -1 = automatic
+        if (value > 1 || value < (tri ? -1 : 0))
+            throw std::string("option value out of range");
+        c.opts[option] = value;
+    });
+}
+int lprt_get_option(lprt_ctx *ctx, lprt_option option, int *value) {
+    return guarded(ctx, [&](CtxBase &c) {
+        if ((int)option < 0 || (int)option >= LPRT_OPT_COUNT || !value)
+            throw std::string("unknown option or null out pointer");
+        *value = c.opts[option];
     });
 }
 int lprt_reset_counters(lprt_ctx *ctx) {
@@ -1082,8 +1202,10 @@ int lprt_set_stage_timing_mask(lprt_ctx *ctx, uint32_t stage_mask) {
         c.timer.mask = stage_mask;
     });
 }
-int lprt_get_stage_times(lprt_ctx *ctx, float ms[LPRT_STAGE_COUNT], uint32_t launches[LPRT_STAGE_COUNT]) {
+int lprt_get_stage_times(lprt_ctx *ctx, float *ms, uint32_t *launches, uint32_t n) {
     return guarded(ctx, [&](CtxBase &c) {
+        if (n != LPRT_STAGE_COUNT)
+            throw std::string("stage arrays must hold LPRT_STAGE_COUNT entries (lprt_get_abi_info().stage_count)");
         c.collect_times();
         for (int i = 0; i < LPRT_STAGE_COUNT; i++) {
             if (ms)

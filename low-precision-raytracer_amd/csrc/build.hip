@@ -890,14 +890,12 @@ template <typename T> void GeometryStore<T>::radix_sort(hipStream_t st, const st
     }
 }
 
-template <typename T> void GeometryStore<T>::build_blas(hipStream_t st) {
+template <typename T> void GeometryStore<T>::build_blas(hipStream_t st, bool use_morton, bool use_local) {
     if (n_tris == 0 || n_vaos == 0) {
         built = true;
         return;
     }
     const uint32_t tb = (n_tris + 255) / 256;
-    const char *bsel = std::getenv("LPRT_BLAS_BUILDER");
-    const bool use_morton = bsel && std::string(bsel) == "morton";
     hipLaunchKernelGGL(k_init_bounds, dim3((6 * n_vaos + 255) / 256), dim3(256), 0, st, d_prim_cbounds.as<int>(), n_vaos);
     hipLaunchKernelGGL(k_tri_prepare, dim3(tb), dim3(256), 0, st, d_vbo32.as<lprt_vertex>(), d_ebo.as<uint32_t>(), n_tris,
                        d_tri_prim.as<uint32_t>(), d_mf32.as<TriRecF32>(), d_tri_bounds.as<float>(), d_prim_cbounds.as<int>());
@@ -924,8 +922,6 @@ template <typename T> void GeometryStore<T>::build_blas(hipStream_t st) {
         hipLaunchKernelGGL(k_iota, dim3(tb), dim3(256), 0, st, d_vals[cur].as<uint32_t>(), n_tris);
         // levels walked by the global sort: until every node of every primitive holds <= LOCAL_MAX triangles
         uint32_t global_levels = max_depth;
-        const char *lsel = std::getenv("LPRT_BLAS_LOCAL");
-        const bool use_local = !(lsel && std::string(lsel) == "0");
         std::vector<LocalJob> jobs;
         if (use_local) {
             global_levels = 0;

@@ -20,7 +20,7 @@ template <typename T> struct GeometryStore {
     void upload(hipStream_t st, const lprt_vertex *vbo, uint32_t nv, const uint32_t *ebo, uint32_t ni, const lprt_mesh_vao *vaos,
                 uint32_t nvaos);
     // compute_m + ObjectBVH for every primitive, all on the device
-    void build_blas(hipStream_t st);
+    void build_blas(hipStream_t st, bool use_morton = false, bool use_local = true); // LPRT_OPT_BLAS_BUILDER / LPRT_OPT_BLAS_LOCAL
     void radix_sort(hipStream_t st, const std::vector<int> &shifts, int &cur);
 };
 

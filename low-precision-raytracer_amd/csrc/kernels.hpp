@@ -6,7 +6,8 @@ namespace lprt {
 
 // trace_kernels.hip
 template <typename T>
-void launch_trace_rays(hipStream_t st, const SceneDev<T> &sc, const lprt_ray *rays, uint32_t n, bool any, lprt_hit *hits, Counters *counters);
+void launch_trace_rays(hipStream_t st, const SceneDev<T> &sc, const lprt_ray *rays, uint32_t n, bool any, bool wide, lprt_hit *hits,
+                       Counters *counters); // wide: the two-levels-per-step BLAS walk (trace.hpp)
 template <typename T>
 void launch_make_objrecs(hipStream_t st, const ObjSlot<T> *slots, const ObjConst<T> *objects, const BlasInfo *blas, const T *roots, uint32_t n,
                          uint32_t n_vaos, ObjRec<T> *out);
@@ -36,15 +37,16 @@ template <typename T> void launch_trace_gi(hipStream_t st, const SceneDev<T> &sc
 
 // svgf.hip
 template <typename T> void launch_depth_gradient(hipStream_t st, const FrameDev<T> &fb);
-template <typename T> void launch_temporal_color(hipStream_t st, const FrameDev<T> &fb, float color_w);
+template <typename T> void launch_temporal_color(hipStream_t st, const FrameDev<T> &fb, float color_w, bool always_test);
 template <typename T> void launch_moments(hipStream_t st, const FrameDev<T> &fb, float moments_w);
-template <typename T> void launch_wavelet(hipStream_t st, const FrameDev<T> &fb, int level);
+template <typename T> void launch_wavelet(hipStream_t st, const FrameDev<T> &fb, int level, bool always_test);
 template <typename T>
 void launch_finalize(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, const V4<T> *gi_colored, const V4<T> *gi_white, V4<T> *taa_next,
                      bool add_colored, bool add_white, bool demodulate, float taa_w, float4 *ext_out, uint32_t ext_first_row, uint32_t ext_rows);
 template <typename T> void launch_copy_last_transform(hipStream_t st, const SceneDev<T> &sc, M4<T> *last_L2W, uint32_t n_objects);
 template <typename T> void launch_read_v4(hipStream_t st, const V4<T> *src, float *dst, uint32_t n, int channels);
 void launch_read_u32(hipStream_t st, const uint32_t *src, float *dst, uint32_t n, bool rgba8);
+void launch_read_u8(hipStream_t st, const uint8_t *src, float *dst, uint32_t n);
 
 // rng.hip
 struct RngStore {

@@ -10,7 +10,6 @@
 // filtered by the same thread: w_z, w_n and h are evaluated once per tap and shared; only w_l differs.
 // Colour and variance of a lobe travel as one {r,g,b,var} vector (one load per tap).
 #include "kernels.hpp"
-#include <cstdlib>
 #include "shade.hpp"
 
 namespace lprt {
@@ -586,29 +585,34 @@ __global__ void k_read_u32(const uint32_t *src, float *dst, uint32_t n, int rgba
     }
 }
 
+__global__ void k_read_u8(const uint8_t *src, float *dst, uint32_t n) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n)
+        dst[p] = (float)src[p];
+}
+
 // ---- launchers -------------------------------------------------------------------------------------------------------
 static inline dim3 grid_for(uint32_t n) { return dim3((n + 255) / 256); }
 
 template <typename T> void launch_depth_gradient(hipStream_t st, const FrameDev<T> &fb) {
     hipLaunchKernelGGL(k_depth_gradient<T>, grid_for(fb.win.npix()), dim3(256), 0, st, fb);
 }
-template <typename T> void launch_temporal_color(hipStream_t st, const FrameDev<T> &fb, float color_w) {
+template <typename T> void launch_temporal_color(hipStream_t st, const FrameDev<T> &fb, float color_w, bool always_test) {
     dim3 grid((fb.win.W + TC_BX - 1) / TC_BX, (fb.win.rows() + TC_BY - 1) / TC_BY);
-    const int always_test = std::getenv("LPRT_SVGF_ALWAYS_TEST") != nullptr; // read per launch: tests flip it
-    hipLaunchKernelGGL(k_temporal_color<T>, grid, dim3(256), 0, st, fb, (T)color_w, always_test);
+    hipLaunchKernelGGL(k_temporal_color<T>, grid, dim3(256), 0, st, fb, (T)color_w, always_test ? 1 : 0);
 }
 template <typename T> void launch_moments(hipStream_t st, const FrameDev<T> &fb, float moments_w) {
     hipLaunchKernelGGL(k_moments<T>, grid_for(fb.win.npix()), dim3(256), 0, st, fb, (T)moments_w);
 }
 // level = 0..4 -> stride 1,2,4,8,16.  Buffer rotation (cuda.hpp:1678-1710 with cv_c in the role of color_inout, which
 // holds the integrated colour): L1 c->b (b = next frame's history), L2 b->a, L3 a->c, L4 c->a, L5 a->c; result in cv_c.
-template <typename T> void launch_wavelet(hipStream_t st, const FrameDev<T> &fb, int level) {
+template <typename T> void launch_wavelet(hipStream_t st, const FrameDev<T> &fb, int level, bool always_test) {
     const uint32_t stride = 1u << level;
     const uint32_t lattice_rows = (fb.win.rows() + stride - 1) / stride; // per phase (upper bound)
     constexpr int WV_BY = WvRows<T>::value;
     const dim3 g((fb.win.W + WV_BX - 1) / WV_BX, stride * ((lattice_rows + WV_BY - 1) / WV_BY)), b(WV_BX * WV_BY);
     const SvgfLobe<T> &a = fb.lobe[0], &w = fb.lobe[1];
-    const int at = std::getenv("LPRT_SVGF_ALWAYS_TEST") != nullptr;
+    const int at = always_test ? 1 : 0;
     switch (level) {
     case 0: hipLaunchKernelGGL((k_wavelet<T, 1>), g, b, 0, st, fb, a.cv_c, a.cv_b, w.cv_c, w.cv_b, a.var_c, a.var_b, w.var_c, w.var_b, at); break;
     case 1: hipLaunchKernelGGL((k_wavelet<T, 2>), g, b, 0, st, fb, a.cv_b, a.cv_a, w.cv_b, w.cv_a, a.var_b, a.var_a, w.var_b, w.var_a, at); break;
@@ -634,11 +638,15 @@ void launch_read_u32(hipStream_t st, const uint32_t *src, float *dst, uint32_t n
     hipLaunchKernelGGL(k_read_u32, grid_for(n), dim3(256), 0, st, src, dst, n, rgba8 ? 1 : 0);
 }
 
+void launch_read_u8(hipStream_t st, const uint8_t *src, float *dst, uint32_t n) {
+    hipLaunchKernelGGL(k_read_u8, grid_for(n), dim3(256), 0, st, src, dst, n);
+}
+
 #define INST(T)                                                                                                        \
     template void launch_depth_gradient<T>(hipStream_t, const FrameDev<T> &);                                          \
-    template void launch_temporal_color<T>(hipStream_t, const FrameDev<T> &, float);                                   \
+    template void launch_temporal_color<T>(hipStream_t, const FrameDev<T> &, float, bool);                             \
     template void launch_moments<T>(hipStream_t, const FrameDev<T> &, float);                                          \
-    template void launch_wavelet<T>(hipStream_t, const FrameDev<T> &, int);                                            \
+    template void launch_wavelet<T>(hipStream_t, const FrameDev<T> &, int, bool);                                      \
     template void launch_finalize<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, const V4<T> *,             \
                                      const V4<T> *, V4<T> *, bool, bool, bool, float, float4 *, uint32_t, uint32_t);  \
     template void launch_copy_last_transform<T>(hipStream_t, const SceneDev<T> &, M4<T> *, uint32_t);                  \

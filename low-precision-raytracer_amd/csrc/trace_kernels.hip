@@ -9,7 +9,7 @@
 namespace lprt {
 
 // ---- lprt_trace_rays: cast_ray<find_any,false> over a batch (cuda.hpp:622-631) -------------------------
-template <typename T, bool ANY, bool COUNT>
+template <typename T, bool ANY, bool COUNT, bool WIDE>
 __global__ void __launch_bounds__(256) k_trace_rays(SceneDev<T> sc, const lprt_ray *rays, uint32_t n, lprt_hit *hits, Counters *counters) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     Cnt<COUNT> cnt;
@@ -18,7 +18,7 @@ __global__ void __launch_bounds__(256) k_trace_rays(SceneDev<T> sc, const lprt_r
         RayT<T> ray;
         ray.o = mk3(cvt<T>(in.source[0]), cvt<T>(in.source[1]), cvt<T>(in.source[2]));
         ray.d = mk3(cvt<T>(in.direction[0]), cvt<T>(in.direction[1]), cvt<T>(in.direction[2]));
-        Isect<T> is = cast_ray<T, ANY, COUNT>(sc, ray, in.skip_vao, in.skip_inobject_offset, cvt<T>(in.min_distance),
+        Isect<T> is = cast_ray<T, ANY, COUNT, WIDE>(sc, ray, in.skip_vao, in.skip_inobject_offset, cvt<T>(in.min_distance),
                                               cvt<T>(in.max_distance), cnt);
         lprt_hit h;
         h.hit = is.hit ? 1u : 0u;
@@ -33,25 +33,29 @@ __global__ void __launch_bounds__(256) k_trace_rays(SceneDev<T> sc, const lprt_r
     flush_counters<COUNT>(cnt, counters);
 }
 
+template <typename T, bool ANY, bool WIDE>
+static void launch_trace_rays_w(hipStream_t st, const SceneDev<T> &sc, const lprt_ray *rays, uint32_t n, lprt_hit *hits, Counters *counters) {
+    dim3 grid((n + 255) / 256), block(256);
+    if (counters)
+        hipLaunchKernelGGL((k_trace_rays<T, ANY, true, WIDE>), grid, block, 0, st, sc, rays, n, hits, counters);
+    else
+        hipLaunchKernelGGL((k_trace_rays<T, ANY, false, WIDE>), grid, block, 0, st, sc, rays, n, hits, counters);
+}
 template <typename T>
-void launch_trace_rays(hipStream_t st, const SceneDev<T> &sc, const lprt_ray *rays, uint32_t n, bool any, lprt_hit *hits, Counters *counters) {
+void launch_trace_rays(hipStream_t st, const SceneDev<T> &sc, const lprt_ray *rays, uint32_t n, bool any, bool wide, lprt_hit *hits, Counters *counters) {
     if (n == 0)
         return;
-    dim3 grid((n + 255) / 256), block(256);
-    if (counters) {
-        if (any)
-            hipLaunchKernelGGL((k_trace_rays<T, true, true>), grid, block, 0, st, sc, rays, n, hits, counters);
-        else
-            hipLaunchKernelGGL((k_trace_rays<T, false, true>), grid, block, 0, st, sc, rays, n, hits, counters);
-    } else {
-        if (any)
-            hipLaunchKernelGGL((k_trace_rays<T, true, false>), grid, block, 0, st, sc, rays, n, hits, counters);
-        else
-            hipLaunchKernelGGL((k_trace_rays<T, false, false>), grid, block, 0, st, sc, rays, n, hits, counters);
-    }
+    if (any && wide)
+        launch_trace_rays_w<T, true, true>(st, sc, rays, n, hits, counters);
+    else if (any)
+        launch_trace_rays_w<T, true, false>(st, sc, rays, n, hits, counters);
+    else if (wide)
+        launch_trace_rays_w<T, false, true>(st, sc, rays, n, hits, counters);
+    else
+        launch_trace_rays_w<T, false, false>(st, sc, rays, n, hits, counters);
 }
-template void launch_trace_rays<float>(hipStream_t, const SceneDev<float> &, const lprt_ray *, uint32_t, bool, lprt_hit *, Counters *);
-template void launch_trace_rays<h16>(hipStream_t, const SceneDev<h16> &, const lprt_ray *, uint32_t, bool, lprt_hit *, Counters *);
+template void launch_trace_rays<float>(hipStream_t, const SceneDev<float> &, const lprt_ray *, uint32_t, bool, bool, lprt_hit *, Counters *);
+template void launch_trace_rays<h16>(hipStream_t, const SceneDev<h16> &, const lprt_ray *, uint32_t, bool, bool, lprt_hit *, Counters *);
 
 // ---- material conversion (CUDAMaterial in DataT); objects and lights are converted by k_build_tlas (scene_dev.hpp) ----
 template <typename T> __global__ void k_convert_materials(const lprt_material *in, MaterialT<T> *out, uint32_t n) {

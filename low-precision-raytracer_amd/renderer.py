@@ -6,6 +6,8 @@ no CPU fallback: if csrc/liblprt_hip.so is missing or no GPU is present this mod
 """
 import ctypes as C
 import os
+import sys
+import weakref
 
 import numpy as np
 
@@ -52,10 +54,13 @@ SYMBOLS = [
     ("lprt_export_history_rows", C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32, _P]),
     ("lprt_import_history_rows", C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32, _P]),
     ("lprt_debug_sample_texture", C.c_int, [_P, C.c_uint32, _P, C.c_uint32, _P]),
-    ("lprt_debug_rng_states", C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_uint32, _P]),
+    ("lprt_debug_rng_states", C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_uint32, _P, C.c_size_t]),
+    ("lprt_set_option", C.c_int, [_P, C.c_int, C.c_int]),
+    ("lprt_get_option", C.c_int, [_P, C.c_int, C.POINTER(C.c_int)]),
+    ("lprt_get_abi_info", None, [_P, C.c_uint32]),
     ("lprt_enable_stage_timing", C.c_int, [_P, C.c_int]),
     ("lprt_set_stage_timing_mask", C.c_int, [_P, C.c_uint32]),
-    ("lprt_get_stage_times", C.c_int, [_P, _P, _P]),
+    ("lprt_get_stage_times", C.c_int, [_P, _P, _P, C.c_uint32]),
     ("lprt_reset_stage_times", C.c_int, [_P]),
     ("lprt_get_blas_info", C.c_int, [_P, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("lprt_read_blas_order", C.c_int, [_P, C.c_uint32, _P, C.c_uint32]),
@@ -86,12 +91,48 @@ def load_library():
             fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
             fn.restype = restype
             fn.argtypes = argtypes
+        check_abi(lib)
         _LIB = lib
     return _LIB
 
 
+def check_abi(lib):
+    """Compare the loaded library's struct sizes and table lengths with this binding's mirror of include/lprt.h: an
+    out-array or struct of the wrong size is an error at load time, never a stray write."""
+    info = abi.AbiInfo()
+    lib.lprt_get_abi_info(C.byref(info), C.sizeof(info))
+    want = abi.expected_abi_info()
+    got = {name: int(getattr(info, name)) for name, _ in abi.AbiInfo._fields_}
+    bad = {k: (got[k], v) for k, v in want.items() if got[k] != v}
+    if bad:
+        raise LprtError(f"liblprt_hip.so does not match this binding's mirror of include/lprt.h (library, binding): {bad}")
+
+
+_LIVE = weakref.WeakSet()  # renderers not yet closed (tests close what a test left open: no GC-time lprt_destroy)
+
+
+def close_all():
+    """Destroy every context that is still open.  Deterministic teardown for test harnesses and at-exit handlers."""
+    for r in list(_LIVE):
+        r.close()
+
+
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def _out(shape, dtype):
+    """Host array the library writes into (its contents are fully overwritten, or it is zero-filled where the callers
+    rely on that).  Test harnesses swap `alloc_out` for an allocator that ends the array at a PROT_NONE page
+    (tests/guarded.py), so that a native write past the end faults at the write."""
+    return alloc_out(shape, dtype)
+
+
+def _zeros(shape, dtype):
+    return np.zeros(shape, dtype=dtype)
+
+
+alloc_out = _zeros
 
 
 class Renderer:
@@ -111,6 +152,7 @@ class Renderer:
             self.h = None
             raise LprtError(f"lprt_create failed ({rc}): {msg}")
         self.scene = None
+        _LIVE.add(self)
 
     # ---- plumbing -------------------------------------------------------------------------------
     def _check(self, rc, what):
@@ -118,11 +160,25 @@ class Renderer:
             raise LprtError(f"{what} failed ({rc}): {self.L.lprt_last_error(self.h).decode()}")
 
     def close(self):
+        """lprt_destroy.  Call it (or use the renderer as a context manager): destruction then happens at a point the
+        caller chose, with the HIP runtime and every stream the context was given still alive."""
         if getattr(self, "h", None):
-            self.L.lprt_destroy(self.h)
-            self.h = None
+            h, self.h = self.h, None
+            _LIVE.discard(self)
+            self.L.lprt_destroy(h)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def __del__(self):
+        # Last resort only.  At interpreter shutdown the HIP runtime (and PyTorch, whose stream the context may have been
+        # given) may already be gone: the process is exiting, so the device memory is left to the driver.
+        if sys is None or sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -164,7 +220,7 @@ class Renderer:
     def sample_texture(self, handle, uv):
         """Device texture fetches at normalised coordinates uv[n, 2] -> float32 [n, 4] (test hook)."""
         uv = np.ascontiguousarray(uv, dtype=np.float32)
-        out = np.zeros((len(uv), 4), dtype=np.float32)
+        out = _out((len(uv), 4), np.float32)
         self._check(self.L.lprt_debug_sample_texture(self.h, handle, _ptr(uv), len(uv), _ptr(out)), "lprt_debug_sample_texture")
         return out
 
@@ -210,7 +266,8 @@ class Renderer:
 
     def read(self, name):
         bid = abi.BUF[name] if isinstance(name, str) else name
-        out = np.empty((self.rows, self.W, abi.BUF_CHANNELS[bid]), dtype=np.float32)
+        shape = (self.rows, self.W, abi.BUF_CHANNELS[bid])
+        out = _out((abi.BUF_PLANES[bid],) + shape if bid in abi.BUF_PLANES else shape, np.float32)
         self._check(self.L.lprt_read_buffer(self.h, bid, _ptr(out), out.size), "lprt_read_buffer")
         return out
 
@@ -222,7 +279,7 @@ class Renderer:
     # ---- ray batches / instrumentation ---------------------------------------------------------------------
     def trace(self, rays, find_any=False):
         rays = np.ascontiguousarray(rays, dtype=abi.RAY_DTYPE)
-        hits = np.zeros(len(rays), dtype=abi.HIT_DTYPE)
+        hits = _out(len(rays), abi.HIT_DTYPE)
         self._check(self.L.lprt_trace_rays(self.h, _ptr(rays), len(rays), int(find_any), _ptr(hits)), "lprt_trace_rays")
         return hits
 
@@ -260,9 +317,18 @@ class Renderer:
         self._check(self.L.lprt_import_history_rows(self.h, groups, first_row, n_rows, C.c_void_p(int(dev_ptr))), "lprt_import_history_rows")
 
     def rng_states(self, seed, first, count):
-        out = np.zeros((count, 6), dtype=np.uint32)
-        self._check(self.L.lprt_debug_rng_states(self.h, int(seed), first, count, _ptr(out)), "lprt_debug_rng_states")
+        out = _out((count, abi.RNG_STATE_WORDS), np.uint32)
+        self._check(self.L.lprt_debug_rng_states(self.h, int(seed), first, count, _ptr(out), out.size), "lprt_debug_rng_states")
         return out
+
+    # ---- behaviour knobs (lprt_option): speed only, never results ------------------------------------------------------
+    def set_option(self, name, value):
+        self._check(self.L.lprt_set_option(self.h, abi.OPTIONS.index(name), int(value)), "lprt_set_option")
+
+    def get_option(self, name):
+        v = C.c_int()
+        self._check(self.L.lprt_get_option(self.h, abi.OPTIONS.index(name), C.byref(v)), "lprt_get_option")
+        return v.value
 
     def enable_stage_timing(self, on=True):
         self._check(self.L.lprt_enable_stage_timing(self.h, int(on)), "lprt_enable_stage_timing")
@@ -277,7 +343,7 @@ class Renderer:
     def stage_times(self):
         ms = (C.c_float * len(abi.STAGES))()
         n = (C.c_uint32 * len(abi.STAGES))()
-        self._check(self.L.lprt_get_stage_times(self.h, ms, n), "lprt_get_stage_times")
+        self._check(self.L.lprt_get_stage_times(self.h, ms, n, len(abi.STAGES)), "lprt_get_stage_times")
         return {s: (float(ms[i]), int(n[i])) for i, s in enumerate(abi.STAGES)}
 
     def reset_stage_times(self):
@@ -290,12 +356,12 @@ class Renderer:
 
     def blas_order(self, vao):
         n = self.blas_info(vao)["n_tris"]
-        out = np.zeros(n, dtype=np.uint32)
+        out = _out(n, np.uint32)
         self._check(self.L.lprt_read_blas_order(self.h, vao, _ptr(out), n), "lprt_read_blas_order")
         return out
 
     def blas_boxes(self, vao):
         n = self.blas_info(vao)["n_nodes"]
-        out = np.zeros((n, 6), dtype=np.float32)
+        out = _out((n, 6), np.float32)
         self._check(self.L.lprt_read_blas_boxes(self.h, vao, _ptr(out), n), "lprt_read_blas_boxes")
         return out

@@ -2,6 +2,8 @@
 import ctypes as C
 import os
 import subprocess
+import sys
+import weakref
 
 import numpy as np
 
@@ -90,6 +92,19 @@ def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def _zeros(shape, dtype):
+    return np.zeros(shape, dtype=dtype)
+
+
+alloc_out = _zeros  # tests/guarded.py swaps in arrays that end at a PROT_NONE page
+_LIVE = weakref.WeakSet()
+
+
+def close_all():
+    for o in list(_LIVE):
+        o.close()
+
+
 class Oracle:
     """CPU restatement of Renderer<DataT> (rt/gui/imgui_window.cu:78-367)."""
 
@@ -102,13 +117,24 @@ class Oracle:
         # default: the CPUs this process may run on, at most 32 (a GPU box shows 256 logical CPUs but grants a share of them:
         # 255 spinning OpenMP workers only get in each other's way)
         self.L.orc_set_threads(self.h, threads or max(1, min(len(os.sched_getaffinity(0)), 32)))
+        _LIVE.add(self)
 
     def close(self):
-        if self.h:
-            self.L.orc_destroy(self.h)
-            self.h = None
+        if getattr(self, "h", None):
+            h, self.h = self.h, None
+            _LIVE.discard(self)
+            self.L.orc_destroy(h)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def __del__(self):
+        if sys is None or sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -134,7 +160,7 @@ class Oracle:
 
     def sample_texture(self, handle, uv):
         uv = np.ascontiguousarray(uv, dtype=np.float32)
-        out = np.zeros((len(uv), 4), dtype=np.float32)
+        out = alloc_out((len(uv), 4), np.float32)
         assert self.L.orc_tex2d(self.h, handle, _ptr(uv), len(uv), _ptr(out)) == 0
         return out
 
@@ -156,14 +182,14 @@ class Oracle:
     def read(self, name):
         bid = abi.BUF[name] if isinstance(name, str) else name
         ch = abi.BUF_CHANNELS[bid]
-        out = np.empty((self.H, self.W, ch), dtype=np.float32)
+        out = alloc_out((self.H, self.W, ch), np.float32)
         rc = self.L.orc_read_buffer(self.h, bid, _ptr(out), out.size)
         assert rc == 0, rc
         return out
 
     def trace(self, rays, find_any=False):
         rays = np.ascontiguousarray(rays, dtype=abi.RAY_DTYPE)
-        hits = np.zeros(len(rays), dtype=abi.HIT_DTYPE)
+        hits = alloc_out(len(rays), abi.HIT_DTYPE)
         self.L.orc_trace_rays(self.h, _ptr(rays), len(rays), int(find_any), _ptr(hits))
         return hits
 

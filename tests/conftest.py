@@ -16,6 +16,31 @@ def pytest_configure(config):
     if not os.path.exists(lib):
         import subprocess
         subprocess.run(["make", "-C", os.path.dirname(lib), "-j8"], check=True, capture_output=True)
+    _install_guarded_out_arrays()
+
+
+def _install_guarded_out_arrays():
+    """Every out-array the bindings hand to native code (product library and oracle) ends at a PROT_NONE page."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import guarded
+    import lprt_amd  # noqa: F401
+    from lprt_amd import renderer
+    from oracle import binding
+    renderer.alloc_out = guarded.empty
+    binding.alloc_out = guarded.empty
+
+
+@pytest.fixture(autouse=True)
+def _deterministic_native_lifetimes():
+    """No context outlives the test that made it: lprt_destroy / orc_destroy run HERE, on the main thread, between tests,
+    with the HIP runtime, PyTorch and every stream still alive -- never from a garbage-collection pass at some
+    arbitrary allocation, and never at interpreter shutdown."""
+    yield
+    mods = sys.modules
+    if "lprt_amd.renderer" in mods:
+        mods["lprt_amd.renderer"].close_all()
+    if "oracle.binding" in mods:
+        mods["oracle.binding"].close_all()
 
 
 def _has_gpu():

@@ -384,9 +384,38 @@ def test_render_phases_and_sample_rows_are_checked(cornell):
         r.set_sample_rows(0, 16)
     with pytest.raises(lprt_amd.LprtError, match="row window"):
         r.set_sample_rows(32, 16)
+    # first_row + n_rows wraps around in 32 bits: rejected, not "inside the window"
+    with pytest.raises(lprt_amd.LprtError, match="row window"):
+        r.set_sample_rows(10, 0xFFFFFFF7)
+    with pytest.raises(lprt_amd.LprtError, match="row window"):
+        r.export_history_rows(10, 0xFFFFFFF7, 0xdead0000)
+    with pytest.raises(lprt_amd.LprtError, match="row window"):
+        r.set_output_target(0xdead0000, 10, 0xFFFFFFF7)
     r.set_sample_rows(16, 8)
     r.set_sample_rows(0, 0)  # back to the whole window
     r.render(fs)
+
+
+def test_options_out_array_sizes_and_null_pointers_are_checked(cornell):
+    import ctypes as C
+    with lprt_amd.Renderer(32, 32, abi.F32) as r:
+        assert [r.get_option(n) for n in abi.OPTIONS] == [-1, -1, 1, 0, 0, 1, 0]
+        r.set_option("wide_walk", 1)
+        assert r.get_option("wide_walk") == 1
+        with pytest.raises(lprt_amd.LprtError, match="out of range"):
+            r.set_option("axis_reject", -1)
+        with pytest.raises(lprt_amd.LprtError, match="out of range"):
+            r.set_option("wide_walk", 2)
+        assert r.L.lprt_set_option(r.h, 99, 0) == -1
+        # sized out-arrays: a wrong length is an error, nothing is written
+        ms = (C.c_float * 4)(1, 2, 3, 4)
+        assert r.L.lprt_get_stage_times(r.h, ms, None, 4) == -1 and list(ms) == [1, 2, 3, 4]
+        out = np.full(12, 7, dtype=np.uint32)
+        assert r.L.lprt_debug_rng_states(r.h, 1, 0, 4, out.ctypes.data_as(C.c_void_p), out.size) == -1 and (out == 7).all()
+        r.set_rdresource(cornell)
+        assert r.L.lprt_get_blas_info(r.h, 0, None, None, None) == -1
+        assert b"null" in r.L.lprt_last_error(r.h)
+    assert r.h is None  # closed by the context manager
 
 
 @pytest.mark.parametrize("prec", [abi.F32, abi.F16])
@@ -501,17 +530,14 @@ def test_degenerate_scenes_render_without_faults(cornell):
 
 
 @pytest.mark.parametrize("prec", [abi.F32, abi.F16])
-def test_axis_rejections_never_change_a_frame(sponza, prec, monkeypatch):
+def test_axis_rejections_never_change_a_frame(sponza, prec):
     """trace.hpp's stationary / overflowed-axis rejections only drop boxes a ray cannot reach: with them switched off
-    (LPRT_NO_AXIS_REJECT: the reference's plain slab test, 2-5x slower in half precision at this scene's scale) the
+    (LPRT_OPT_AXIS_REJECT = 0: the reference's plain slab test, 2-5x slower in half precision at this scene's scale) the
     frames are bit-identical, in both precisions, over two frames of the 262 k-triangle atrium."""
     outs = []
     for off in (False, True):
-        if off:
-            monkeypatch.setenv("LPRT_NO_AXIS_REJECT", "1")
-        else:
-            monkeypatch.delenv("LPRT_NO_AXIS_REJECT", raising=False)
         r = lprt_amd.Renderer(256, 144, prec)
+        r.set_option("axis_reject", 0 if off else 1)
         r.load_scene(sponza)
         for _ in range(2):
             r.set_scene(sponza)
@@ -524,18 +550,15 @@ def test_axis_rejections_never_change_a_frame(sponza, prec, monkeypatch):
 
 @pytest.mark.parametrize("prec", [abi.F32, abi.F16])
 @pytest.mark.parametrize("scene_name", ["cornell", "textured"])
-def test_untested_window_sums_of_the_temporal_filter_never_change_a_frame(scene_name, prec, monkeypatch):
+def test_untested_window_sums_of_the_temporal_filter_never_change_a_frame(scene_name, prec):
     """k_temporal_color sums its 9x9 window without the per-sample finite tests when a workgroup's staged tile holds no
     inf/NaN (in half with packed adds/multiplies, two channels per instruction).  Forcing the tested form
-    (LPRT_SVGF_ALWAYS_TEST) must give bit-identical lobes and frames over three frames."""
+    (LPRT_OPT_SVGF_ALWAYS_TEST) must give bit-identical lobes and frames over three frames."""
     sc = scenes.SCENES[scene_name]()
     outs = []
     for forced in (False, True):
-        if forced:
-            monkeypatch.setenv("LPRT_SVGF_ALWAYS_TEST", "1")
-        else:
-            monkeypatch.delenv("LPRT_SVGF_ALWAYS_TEST", raising=False)
         r = lprt_amd.Renderer(200, 120, prec)
+        r.set_option("svgf_always_test", int(forced))
         r.load_scene(sc)
         for _ in range(3):
             r.set_scene(sc)

@@ -241,14 +241,14 @@ def test_tlas_tree_walk_with_many_instances():
     assert o.trace(rays, False)["hit"].mean() > 0.2
 
 
-def test_local_subtree_ordering_equals_the_all_global_build(sponza, small_scene, monkeypatch):
+def test_local_subtree_ordering_equals_the_all_global_build(sponza, small_scene):
     """build.hip: below 1024 triangles per node one workgroup finishes the subtree's median ordering in LDS (bitonic sort
     of sub-node | key | position); the permutation must be the one the level-by-level global radix sorts produce."""
     for sc in (small_scene, sponza):
         orders = {}
         for mode in ("0", "1"):
-            monkeypatch.setenv("LPRT_BLAS_LOCAL", mode)
             r = lprt_amd.Renderer(16, 16, abi.F32)
+            r.set_option("blas_local", int(mode))
             r.set_rdresource(sc)
             orders[mode] = [r.blas_order(v) for v in range(len(sc.vaos))]
             r.close()

@@ -72,6 +72,40 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert b"gfx950" in lib.lprt_version()
 
 
+def test_abi_info_matches_the_binding_and_option_names_follow_the_header():
+    """lprt_get_abi_info: what renderer.check_abi compares at load time (struct sizes, stage / buffer / option counts,
+    words per RNG state) -- and the binding's option names in the header's enum order."""
+    lib = renderer.load_library()
+    info = abi.AbiInfo()
+    lib.lprt_get_abi_info(C.byref(info), C.sizeof(info))
+    for k, v in abi.expected_abi_info().items():
+        assert getattr(info, k) == v, k
+    # a caller that knows a shorter struct gets only that many bytes
+    short = (C.c_uint32 * 6)(*([0xdeadbeef] * 6))
+    lib.lprt_get_abi_info(short, 16)
+    assert short[1] == len(abi.STAGES) and short[4] == 0xdeadbeef
+    names = re.findall(r"LPRT_OPT_([A-Z_]+)\s*=\s*(\d+)", open(HEADER).read())
+    assert [n.lower() for n, _ in names if n != "COUNT"] == abi.OPTIONS
+    assert [int(v) for _, v in names] == list(range(len(names)))
+    assert C.sizeof(abi.FrameSettings) == info.sizeof_frame_settings
+
+
+def test_guard_paged_out_arrays_fault_at_the_first_byte_past_the_end():
+    """tests/guarded.py: the arrays the bindings hand to native code in this test suite end at a PROT_NONE page."""
+    import subprocess
+    import sys
+    import guarded
+    a = guarded.empty((3, 5), np.float32)
+    assert a.shape == (3, 5) and (a.ctypes.data + a.nbytes) % 4096 == 0 and not a.any()
+    a[...] = 7
+    code = ("import sys, ctypes, numpy as np; sys.path.insert(0, %r); import guarded; a = guarded.empty(100, np.float32); "
+            "ctypes.memset(a.ctypes.data, 0, a.nbytes); sys.stdout.write('inside ok'); sys.stdout.flush(); "
+            "ctypes.memset(a.ctypes.data, 0, a.nbytes + 1)") % os.path.dirname(os.path.abspath(__file__))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert p.stdout == "inside ok" and p.returncode == -11  # SIGSEGV at the overrun, not later
+    assert renderer.alloc_out is guarded.empty  # installed by conftest.py for the whole suite
+
+
 def test_create_fails_loudly_without_a_gpu_or_with_bad_arguments():
     lib = renderer.load_library()
     h = C.c_void_p()

@@ -8,8 +8,8 @@ for name in ("sponza_like", "small_test", "cornell", "instanced_field"):
     sc = scenes.SCENES[name]()
     orders, times = {}, {}
     for mode in ("0", "1"):
-        os.environ["LPRT_BLAS_LOCAL"] = mode
         r = lprt_amd.Renderer(64, 64, abi.F32)
+        r.set_option("blas_local", int(mode))
         r.set_rdresource(sc)            # builds once (warm-up: allocations)
         r.enable_stage_timing(True)
         r.reset_stage_times()

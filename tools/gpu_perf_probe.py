@@ -30,10 +30,9 @@ def main():
             fs = abi.default_settings(spp=4)
             for rep in range(2):
                 for mode in ("0", "1"):
-                    os.environ["LPRT_TLAS_MODE"] = mode
+                    r.set_option("tlas_mode", int(mode))
                     ms, st = timed(r, sc, fs, frames=8)
                     print(f"cornell prec={prec} tlas_mode={mode} rep={rep}: {ms:.3f} ms  primary={st['primary']} di1={st['trace_di1']} gi={st['trace_gi']} di2={st['trace_di2']}", flush=True)
-            os.environ.pop("LPRT_TLAS_MODE", None)
             r.close()
     if "sponza" in which:
         sc = scenes.sponza_like()
@@ -44,10 +43,9 @@ def main():
             for rebuild in (0, 1):
                 fs = abi.default_settings(spp=8); fs.rebuild_blas = rebuild
                 for mode in ("0", "1"):
-                    os.environ["LPRT_TLAS_MODE"] = mode
+                    r.set_option("tlas_mode", int(mode))
                     ms, st = timed(r, sc, fs, frames=5)
                     print(f"sponza_like 1080p 8spp prec={prec} rebuild={rebuild} tlas_mode={mode}: {ms:.3f} ms/frame {rays/ms/1e3:.0f} Mray/s  {json.dumps(st)}", flush=True)
-            os.environ.pop("LPRT_TLAS_MODE", None)
             r.close()
     if "sponza_parity" in which:
         from oracle.binding import Oracle
