@@ -182,7 +182,8 @@ class Oracle:
     def read(self, name):
         bid = abi.BUF[name] if isinstance(name, str) else name
         ch = abi.BUF_CHANNELS[bid]
-        out = alloc_out((self.H, self.W, ch), np.float32)
+        shape = (self.H, self.W, ch)
+        out = alloc_out((abi.BUF_PLANES[bid],) + shape if bid in abi.BUF_PLANES else shape, np.float32)
         rc = self.L.orc_read_buffer(self.h, bid, _ptr(out), out.size)
         assert rc == 0, rc
         return out

@@ -54,6 +54,51 @@ template <typename T> int read_buffer(Renderer<T> &r, int id, float *dst, size_t
         if (!need(1)) return LPRT_ERR_INVALID;
         for (size_t i = 0; i < N; i++) dst[i] = float(r.g_offset[i]);
         return 0;
+    // the commands the last shade of the frame left (rt/rtrt/cuda.hpp:1014-1032), for the ray replay of tests/replay.py
+    case LPRT_BUF_GI_DIRECTION:
+        if (!need(4)) return LPRT_ERR_INVALID;
+        if (r.dbg_gi_direction.size() != N) return LPRT_ERR_INVALID; // no frame rendered yet
+        read_vec4(r.dbg_gi_direction, N, dst);
+        return 0;
+    case LPRT_BUF_LIGHT_DIR_MAXT: // [4 slots][N][4]
+        if (!need(16)) return LPRT_ERR_INVALID;
+        for (size_t s = 0; s < 4; s++)
+            for (size_t i = 0; i < N; i++) {
+                const auto &c = r.trace_light_commands[i * 4 + s];
+                const bool on = c.slot != UINT8_MAX;
+                for (int k = 0; k < 3; k++)
+                    dst[4 * (s * N + i) + size_t(k)] = on ? float(c.direction[k]) : 0.f;
+                dst[4 * (s * N + i) + 3] = on ? float(c.maximum_t) : 0.f;
+            }
+        return 0;
+    case LPRT_BUF_LIGHT_MASK:
+        if (!need(1)) return LPRT_ERR_INVALID;
+        for (size_t i = 0; i < N; i++) {
+            unsigned m = 0;
+            for (size_t s = 0; s < 4; s++)
+                m |= (r.trace_light_commands[i * 4 + s].slot != UINT8_MAX ? 1u : 0u) << s;
+            dst[i] = float(m);
+        }
+        return 0;
+    case LPRT_BUF_SHADE_POSITION: // source of the round-1 shadow rays = the commands' own source
+        if (!need(3)) return LPRT_ERR_INVALID;
+        for (size_t i = 0; i < N; i++) {
+            const decltype(r.trace_light_commands.data()) c0 = &r.trace_light_commands[i * 4];
+            int first = -1;
+            for (int s = 3; s >= 0; s--)
+                if (c0[s].slot != UINT8_MAX)
+                    first = s;
+            for (int k = 0; k < 3; k++)
+                dst[3 * i + size_t(k)] = first >= 0 ? float(c0[first].source[k]) : 0.f;
+        }
+        return 0;
+    case LPRT_BUF_SKIP:
+        if (!need(2)) return LPRT_ERR_INVALID;
+        for (size_t i = 0; i < N; i++) {
+            dst[2 * i] = float(r.skips[i].vao_index);
+            dst[2 * i + 1] = float(r.skips[i].inobject_offset);
+        }
+        return 0;
     default: return LPRT_ERR_INVALID;
     }
 }

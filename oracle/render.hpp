@@ -287,6 +287,7 @@ template <typename T> class Renderer {
         }
     } svgf_colored, svgf_white;
     std::vector<Vec3<T>> raw_gi_colored, raw_gi_white, raw_color; // read-back copies
+    std::vector<Vec4<T>> dbg_gi_direction; // read-back copy of the last sample's TraceGICommand directions (w = 1: cast)
     std::vector<Vec4<float>> output;
     uint64_t frame_index = 0;
     Counters counters;
@@ -1641,6 +1642,13 @@ template <typename T> class Renderer {
             else
                 shade<true, true>(0, seed_of(s, 1));
             stage_seconds[LPRT_STAGE_SHADE1] += tm.lap();
+            dbg_gi_direction.assign(N, Vec4<T>());
+            for (size_t i = 0; i < N; i++)
+                if (gi_valid[i]) {
+                    const Vec3<T> &d = trace_gi_commands[i].direction;
+                    dbg_gi_direction[i] = mk4(d[0], d[1], d[2], T(1.f));
+                }
+            tm.lap();
             trace_di_light();
             stage_seconds[LPRT_STAGE_TRACE_DI1] += tm.lap();
             accumulate_di_light(0);

@@ -9,6 +9,7 @@ import lprt_amd
 from lprt_amd import abi, scenes, dist
 from oracle.binding import Oracle
 from conftest import rel_l2
+import replay
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -52,9 +53,35 @@ def test_c1_golden_cornell_256(cornell, prec):
             assert rel_l2(r.read(name), o.read(name)) < TOL[prec], name
 
 
+PRE_DENOISE = ["INTENSITY0", "INTENSITY1", "RAW_COLOR", "RAW_GI_COLORED", "RAW_GI_WHITE"]
+POST_DENOISE = ["MUL_GI_COLORED", "MUL_GI_WHITE", "COLOR_INPROGRESS", "OUTPUT"]
+
+
+def assert_planes_ray_by_ray(r, o, c, prec, kept_l2, kept_px, max_outliers):
+    """Frame parity with the pixels set aside where tests/replay.py found a ray that reported something else (c: its
+    classification).  Pre-denoise planes: over the other pixels, relative L2 <= kept_l2 and per-pixel relative error
+    <= kept_px except for at most max_outliers pixels (an `other ray` hit of the same triangle at a grazing angle).  With no
+    such pixel at all, every plane, denoised ones included, is held to the north star's whole-buffer tolerance."""
+    for name in PRE_DENOISE:
+        a, b = r.read(name), o.read(name)
+        keep = ~(c["last_sample"] if name in ("INTENSITY0", "INTENSITY1") else c["any"])
+        assert rel_l2(a[keep], b[keep]) <= kept_l2, (name, rel_l2(a[keep], b[keep]))
+        e = replay.pixel_error(a, b, 1e-3)[keep]
+        assert int((e > kept_px).sum()) <= max_outliers, (name, float(e.max()), int((e > kept_px).sum()))
+    if not c["any"].any():
+        for name in RADIANCE:
+            assert rel_l2(r.read(name), o.read(name)) < TOL[prec], name
+
+
 @pytest.mark.parametrize("prec", [abi.F32, abi.F16])
 @pytest.mark.parametrize("scene_name,W,H", [("cornell", 160, 96), ("small_test", 200, 120), ("textured", 192, 108), ("instanced_field", 160, 90)])
 def test_every_buffer_matches_oracle(scene_name, W, H, prec):
+    """One frame, every plane.  Single precision: integer planes bit-exact, every radiance plane within 1e-3 over ALL pixels
+    (no ray of these scenes finds anything else than in the oracle).  Half precision: a few rays per frame do (primary
+    rays at silhouettes, GI rays whose direction differs in its last bit, ties at half resolution of t: 0.1 % of the pixels
+    of `instanced_field`); tests/replay.py names those pixels by replaying every ray of the frame on both sides, their
+    number is bounded, and every other pixel of the pre-denoise planes agrees to 1e-4 -- where the rays agree, the
+    arithmetic does."""
     sc = scenes.SCENES[scene_name]()
     r, o = render_pair(sc, W, H, prec, frames=1, spp=1)
     if prec == abi.F32:  # integer planes bit-exact
@@ -62,20 +89,86 @@ def test_every_buffer_matches_oracle(scene_name, W, H, prec):
             assert np.array_equal(r.read(name), o.read(name)), name
         for name in ("G_POSITION", "G_NORMAL_DEPTH", "G_TANGENT", "G_UV0UV1", "ALBEDO"):
             assert rel_l2(r.read(name), o.read(name)) < 1e-6, name
-    else:
-        assert (r.read("G_OBJID") != o.read("G_OBJID")).mean() < 2e-3
-    for name in RADIANCE:
-        a, b = r.read(name), o.read(name)
-        assert np.array_equal(np.isfinite(a), np.isfinite(b)) or prec == abi.F16, name
-        if prec == abi.F16 and scene_name in ("textured", "instanced_field"):
-            # fp16 box culling depends on the tree topology, which the reference leaves to std::nth_element: a handful
-            # of grazing GI rays land elsewhere in one tree than in the other (on the bright sky instead of geometry; on
-            # another instance).  The sparse lobe buffers are dominated by those few pixels (0.04 % of them here), so
-            # the 0.5 % worst pixels are set aside before the L2 bound.
-            d = np.abs(np.nan_to_num(a) - np.nan_to_num(b)).sum(axis=-1).reshape(-1)
-            keep = d <= np.quantile(d, 0.995)
-            a, b = a.reshape(-1, a.shape[-1])[keep], b.reshape(-1, b.shape[-1])[keep]
-        assert rel_l2(a, b) < TOL[prec], name
+        for name in RADIANCE:
+            a, b = r.read(name), o.read(name)
+            assert np.array_equal(np.isfinite(a), np.isfinite(b)), name
+            assert rel_l2(a, b) < TOL[prec], name
+        return
+    probe_g, probe_o = lprt_amd.Renderer(W, H, prec), Oracle(W, H, prec)
+    probe_g.load_scene(sc)
+    probe_o.load_scene(sc)
+    c = replay.classify(r, o, sc, prec, probe_g, probe_o, frame=0, spp=1)
+    assert c["any"].mean() < 2.5e-3, int(c["any"].sum())
+    assert sum(int(m.sum()) for m in c["gi_cull"]) <= 2
+    assert_planes_ray_by_ray(r, o, c, prec, kept_l2=1e-4, kept_px=1e-2, max_outliers=0)
+    assert rel_l2(r.read("OUTPUT"), o.read("OUTPUT")) < TOL[prec]  # what is displayed, over all pixels
+
+
+@pytest.mark.parametrize("prec", [abi.F32, abi.F16])
+def test_atrium_frames_with_per_frame_rebuild_match_oracle_ray_by_ray(sponza, prec):
+    """BASELINE configs[3] workload (262 k-triangle atrium, every BLAS rebuilt on the GPU inside each frame) against the
+    oracle: two frames at 2 spp, reduced to 256x144 so the oracle finishes in seconds.
+
+    The atrium is where rays can legally find something else than in the oracle: its GI directions come out of device
+    transcendentals that differ from libm in the last bit (a different ray), and in half precision t has 11 bits at
+    distances of 5-30 m, so which of several triangles at the "same" t wins depends on traversal order, which depends on
+    the hierarchy (the reference leaves that to std::nth_element).  Every ray of every sample is therefore replayed on both
+    sides (tests/replay.py, ~320 k rays per frame) and the claim is split in two:
+      1. how many pixels see a ray that found something else, by kind -- bounded; in single precision a handful (all of the
+         `other ray` kind, none from box culling), in half precision a few per cent;
+      2. everywhere else the pre-denoise radiance planes agree to 2e-4 (fp32: libm vs device rounding) / 1e-4 (fp16),
+         i.e. the arithmetic is the oracle's.
+    What is displayed (OUTPUT, COLOR_INPROGRESS) meets the north star's whole-buffer tolerance over all pixels."""
+    W, H, spp = 256, 144, 2
+    o, probe_o = Oracle(W, H, prec), Oracle(W, H, prec)
+    r, probe_g = lprt_amd.Renderer(W, H, prec), lprt_amd.Renderer(W, H, prec)
+    for x in (o, probe_o, r, probe_g):
+        x.load_scene(sponza)
+    npx = W * H
+    for f in range(2):
+        fs = abi.default_settings(spp=spp)
+        fs.rebuild_blas = 1
+        o.set_scene(sponza)
+        o.render_frame(fs)
+        r.set_scene(sponza)
+        r.render(fs)
+        c = replay.classify(r, o, sponza, prec, probe_g, probe_o, f, spp, rebuild_blas=1)
+        count = lambda k: max(int(m.sum()) for m in c[k])
+        if prec == abi.F32:
+            assert int(c["primary"].sum()) <= 2 and int(c["shadow0"].sum()) <= 2
+            assert count("gi_cull") == 0, "identical rays at different t: a traversal bug, not a tie"
+            assert count("gi") <= 8 and count("shadow1") <= 8 and int(c["any"].sum()) <= 16
+            assert_planes_ray_by_ray(r, o, c, prec, kept_l2=2e-4, kept_px=1e-2, max_outliers=3)
+            for name in ("INTENSITY0", "RAW_COLOR", "MUL_GI_COLORED", "MUL_GI_WHITE", "COLOR_INPROGRESS", "OUTPUT"):
+                assert rel_l2(r.read(name), o.read(name)) < TOL[prec], (f, name)  # over all pixels
+        else:
+            assert c["primary"].mean() < 0.025 and c["shadow0"].mean() < 3e-3
+            assert count("gi") < 0.025 * npx and count("gi_cull") < 5e-3 * npx and count("shadow1") < 5e-3 * npx
+            assert c["any"].mean() < 0.05
+            assert_planes_ray_by_ray(r, o, c, prec, kept_l2=1e-4, kept_px=1e-2, max_outliers=0)
+            for name in ("COLOR_INPROGRESS", "OUTPUT"):
+                assert rel_l2(r.read(name), o.read(name)) < TOL[prec], (f, name)
+
+
+@pytest.mark.parametrize("prec", [abi.F32, abi.F16])
+def test_rebuilding_every_blas_inside_the_frame_changes_nothing(sponza, prec):
+    """lprt_frame_settings.rebuild_blas (config C4): three frames with the BLAS set rebuilt on the GPU before each one are
+    bit-identical to three frames over the BLAS built once -- the build is deterministic and nothing of the old hierarchy
+    leaks into a frame."""
+    outs = []
+    for rebuild in (0, 1):
+        with lprt_amd.Renderer(256, 144, prec) as r:
+            r.load_scene(sponza)
+            for _ in range(3):
+                fs = abi.default_settings(spp=2)
+                fs.rebuild_blas = rebuild
+                r.set_scene(sponza)
+                r.render(fs)
+            outs.append([r.read(n) for n in ("OUTPUT", "G_OFFSET", "INTENSITY1", "MUL_GI_WHITE")])
+            if rebuild:
+                assert r.blas_info(0)["n_tris"] == sponza.vaos[0][3] // 3
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b, equal_nan=True)
 
 
 @pytest.mark.parametrize("prec", [abi.F32, abi.F16])

@@ -55,7 +55,7 @@ def test_fp32_hit_records_match_oracle(scene_name, n):
     r = lprt_amd.Renderer(16, 16, abi.F32)
     r.load_scene(sc)
     rays = random_rays(sc, n, 11, 1e-4)
-    for any_hit in (False, True):
+    for any_hit in (False, True):  # any-hit batches take the walk the frame kernels take: two levels per step on the atrium
         compare_hits(o.trace(rays, any_hit), r.trace(rays, any_hit), any_hit, 0.01)
 
 
@@ -77,6 +77,41 @@ def test_fp16_hit_records_match_oracle(scene_name):
     assert same.sum() >= 0.99 * both.sum()
     assert np.array_equal(ho["t"][same], hg["t"][same])
     assert (o.trace(rays, True)["hit"] != r.trace(rays, True)["hit"]).mean() < 1e-3
+
+
+@pytest.mark.parametrize("prec", [abi.F32, abi.F16])
+def test_two_level_walk_reports_the_hits_of_the_one_level_walk(sponza, prec):
+    """The walk the shadow rays of deep BLAS trees take by default (trace.hpp, WIDE: grandchild boxes tested straight from
+    the two adjacent child records), at hit-record level on the 262 k-triangle atrium: LPRT_OPT_WIDE_WALK = 1 sends
+    lprt_trace_rays through it for any-hit AND closest-hit batches.  Against the one-level walk (HIP vs HIP): identical
+    visibility, identical closest hits.  Against the oracle: what the one-level walk is held to."""
+    rays = random_rays(sponza, 40000, 13, 1e-4 if prec == abi.F32 else 0.1)
+    o = Oracle(16, 16, prec)
+    o.load_scene(sponza)
+    hits = {}
+    for wide in (0, 1):
+        with lprt_amd.Renderer(16, 16, prec) as r:
+            r.set_option("wide_walk", wide)
+            r.load_scene(sponza)
+            r.enable_counters(True)
+            hits[wide] = (r.trace(rays, False), r.trace(rays, True))
+            assert r.counters()["rays"] == 2 * len(rays)
+    for any_hit in (0, 1):
+        a, b = hits[0][any_hit], hits[1][any_hit]
+        assert np.array_equal(a["hit"], b["hit"])
+        if not any_hit:
+            same = (a["inscene_objid"] == b["inscene_objid"]) & (a["inobject_offset"] == b["inobject_offset"])
+            assert (~same).sum() <= 0.002 * len(rays)           # traversal order differs: ties only
+            if prec == abi.F32:
+                assert np.array_equal(a["t"][~same], b["t"][~same])
+            else:  # the running closest t is kept in half: "the same t" is the same to a few half ulps
+                assert np.allclose(a["t"][~same], b["t"][~same], rtol=4e-3, atol=0)
+            assert np.array_equal(a["t"][same], b["t"][same]) and np.array_equal(a["barycentric"][same], b["barycentric"][same])
+        ho = o.trace(rays, bool(any_hit))
+        if prec == abi.F32:
+            compare_hits(ho, b, bool(any_hit), 0.01)
+        else:
+            assert (ho["hit"] != b["hit"]).mean() < 0.02
 
 
 def test_golden_ray_batch(small_scene):
