@@ -571,6 +571,20 @@ def with_instance_transforms(sc, transforms):
     return out
 
 
+def moving_cornell(k, base=None, climb=0.02):
+    """Frame k of a Cornell-box sequence in which everything moves (the animation path of rt/rtrt/hierarchy.hpp:81-149 as
+    the scene manager would hand it over): the tall box turns 6 degrees per frame, the short box slides, and the camera
+    dollies in while drifting right and UP (climb per frame), so that reprojection moves history taps across image rows."""
+    base = base or cornell_box()
+    tall = translate((-0.33, -0.4, -0.3)) @ rotate_y(17.0 + 6.0 * k) @ scale((0.6, 1.2, 0.6))
+    short = translate((0.33 - 0.05 * k, -0.7, 0.3 + 0.03 * k)) @ rotate_y(-18.0) @ scale((0.6, 0.6, 0.6))
+    sc = with_instance_transforms(base, {5: tall, 6: short})
+    eye = np.array([0.05 * k, climb * k, 3.5 - 0.1 * k])
+    w2v = look_at(eye, (0, 0, 0), (0, 1, 0))
+    sc.camera_W2V, sc.camera_L2W = w2v.astype(np.float32), np.linalg.inv(w2v).astype(np.float32)
+    return sc
+
+
 def write_blob(sc, width, height, path):
     """Flat little-endian dump of what the loader + scene manager hand to the renderer (examples/compat_demo.cpp
     reads it): "LPRTSCN1", six uint32 counts, then vertices, indices, VAOs, materials, objects, AABBs, lights, camera,

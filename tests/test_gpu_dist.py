@@ -19,7 +19,7 @@ def _free_port():
     return p
 
 
-def _rank(rank, world, port, W, H, frames, trace_halo, q):
+def _rank(rank, world, port, W, H, frames, trace_halo, moving, q):
     import torch
     import torch.distributed as tdist
     import lprt_amd
@@ -29,26 +29,29 @@ def _rank(rank, world, port, W, H, frames, trace_halo, q):
     tdist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     sc = scenes.cornell_box()
-    wb, we = dist.window_rows(H, world, rank)
+    halo = dist.HALO_ROWS + (12 if moving else 0)  # 68 rows + the vertical motion per frame
+    wb, we = dist.window_rows(H, world, rank, halo)
     r = lprt_amd.Renderer(W, H, abi.F32, device=0, row_begin=wb, row_end=we)
     r.set_stream(torch.cuda.current_stream().cuda_stream)
-    frame = dist.ShardedFrame(W, H, rank, world, torch.device("cuda", 0), backend="gloo", trace_halo=trace_halo)
+    frame = dist.ShardedFrame(W, H, rank, world, torch.device("cuda", 0), backend="gloo", halo=halo, trace_halo=trace_halo)
     frame.attach(r)
     r.load_scene(sc)
     out = []
-    for _ in range(frames):
-        r.set_scene(sc)
+    for k in range(frames):
+        r.set_scene(scenes.moving_cornell(k, sc, climb=0.06) if moving else sc)
         moved = frame.render(r, abi.default_settings(spp=1))
         img = frame.all_gather()
         torch.cuda.synchronize()
         out.append(img.cpu().numpy().copy())
     q.put((rank, out, moved))
     tdist.barrier()
+    r.close()  # while torch's stream and the HIP runtime are alive
     tdist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,trace_halo", [(2, True), (2, False), (3, False)])  # 3 ranks: the middle one has two neighbours
-def test_ranks_render_exchange_gather_equal_one_context(world, trace_halo):
+# 3 ranks: the middle one has two neighbours; moving: objects move, the camera dollies and climbs, history taps cross strips
+@pytest.mark.parametrize("world,trace_halo,moving", [(2, True, False), (2, False, False), (3, False, False), (3, False, True), (2, True, True)])
+def test_ranks_render_exchange_gather_equal_one_context(world, trace_halo, moving):
     import torch.multiprocessing as mp
     import lprt_amd
     from lprt_amd import abi, scenes
@@ -56,7 +59,7 @@ def test_ranks_render_exchange_gather_equal_one_context(world, trace_halo):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank, args=(r, world, port, W, H, frames, trace_halo, q)) for r in range(world)]
+    procs = [ctx.Process(target=_rank, args=(r, world, port, W, H, frames, trace_halo, moving, q)) for r in range(world)]
     for p in procs:
         p.start()
     got = [q.get(timeout=300) for _ in range(world)]
@@ -67,8 +70,8 @@ def test_ranks_render_exchange_gather_equal_one_context(world, trace_halo):
     full = lprt_amd.Renderer(W, H, abi.F32)
     full.load_scene(sc)
     want = []
-    for _ in range(frames):
-        full.set_scene(sc)
+    for k in range(frames):
+        full.set_scene(scenes.moving_cornell(k, sc, climb=0.06) if moving else sc)
         full.render(abi.default_settings(spp=1))
         want.append(full.read("OUTPUT"))
     for rank, out, moved in got:

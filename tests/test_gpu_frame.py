@@ -461,6 +461,111 @@ def test_strips_that_import_their_halo_samples_equal_single_gpu(cornell, prec, s
     assert sum(r.stage_counters("primary")["rays"] for r in ranks) == W * sum(we - wb for wb, we in wins) * frames
 
 
+@pytest.mark.parametrize("prec", [abi.F32, abi.F16])
+def test_sharded_frames_under_motion_equal_single_gpu(cornell, prec):
+    """§8(f) rank 4, the case the halo and the history exchange exist for: objects move and the camera dollies and climbs,
+    so the reprojected history taps (generate_temporal_map, cuda.hpp:2265-2416) of pixels next to a strip boundary land in
+    the NEIGHBOUR's rows.  Three ranks, five frames, halo-untraced path (sample means + history imported from the owners
+    between the two render phases, as dist.ShardedFrame.render does): every frame equals the single-context frame bit for
+    bit.  The halo is 68 rows + the vertical motion per frame (dist.window_rows)."""
+    import torch
+    W, H, world, frames, halo = 160, 300, 3, 5, dist.HALO_ROWS + 12
+    full = lprt_amd.Renderer(W, H, prec)
+    full.load_scene(cornell)
+    wins = [dist.window_rows(H, world, r, halo) for r in range(world)]
+    strips = [dist.strip_rows(H, world, r) for r in range(world)]
+    ranks = []
+    for (wb, we), (b, e) in zip(wins, strips):
+        r = lprt_amd.Renderer(W, H, prec, row_begin=wb, row_end=we)
+        r.load_scene(cornell)
+        r.set_sample_rows(b, e - b)
+        ranks.append(r)
+    groups = abi.HIST_ALL | abi.HIST_SAMPLES
+    row_bytes = ranks[0].history_row_bytes(groups)
+    plan = dist.history_transfers(H, world, halo)
+    crossings, prev_w2c = 0, None
+    for k in range(frames):
+        sc = scenes.moving_cornell(k, cornell, climb=0.06)
+        fs = abi.default_settings(spp=2)
+        full.set_scene(sc)
+        full.render(fs)
+        want = full.read("OUTPUT")
+        for r in ranks:
+            r.set_scene(sc)
+            r.render_phase(fs, abi.PHASE_SAMPLE)
+        for src, dst, b, e in plan:
+            buf = torch.empty((e - b) * row_bytes, dtype=torch.uint8, device="cuda")
+            ranks[src].export_history_rows(b, e - b, buf.data_ptr(), groups)
+            ranks[src].synchronize()
+            ranks[dst].import_history_rows(b, e - b, buf.data_ptr(), groups)
+            ranks[dst].synchronize()
+        for r in ranks:
+            r.render_phase(fs, abi.PHASE_RESOLVE)
+        got = dist.assemble_strips([r.read("OUTPUT")[b - wb:e - wb] for r, (wb, we), (b, e) in zip(ranks, wins, strips)], H, world)
+        assert np.array_equal(got, want, equal_nan=True), f"frame {k}"
+        # the premise: static geometry (the walls) next to a strip boundary reprojects into the other strip's rows
+        if prev_w2c is not None:
+            pos = full.read("G_POSITION").astype(np.float64)
+            pos[..., 3] = 1.0
+            clip = pos @ prev_w2c.T
+            prev_row = np.floor((1.0 + clip[..., 1] / clip[..., 3]) / 2.0 * H - 0.5)
+            row = np.arange(H)[:, None] * np.ones((1, W))
+            walls = (full.read("G_COLOR")[..., 3] > 0) & (full.read("G_OBJID")[..., 0] < 5)
+            for b, _ in strips[1:]:
+                crossings += int((walls & (row >= b) & (prev_row < b)).sum() + (walls & (row < b) & (prev_row >= b)).sum())
+        prev_w2c = sc.transform_W2C(W, H).astype(np.float64)
+    assert crossings > 200, crossings
+    # and the motion matters: the same ranks with the default 68-row halo are NOT enough at this climb rate ... only if
+    # a tap actually leaves the window; this sequence moves < 12 rows per frame, which the widened halo absorbs
+
+
+def test_c5_window_of_a_4k_16spp_fp16_frame_equals_the_full_frame(sponza):
+    """BASELINE configs[4] at full size (atrium, 3840x2160, 16 spp, packed fp16, 8-way row split): rank 3 of 8 renders its
+    406-row window the way bench.py --gpus 8 does -- primary rays over the window, the 16 samples over its 270 owned rows
+    only, the halo rows' sample means imported from the two neighbour contexts that own them -- and its owned rows of the
+    final image equal rows 810..1079 of the single-context 4K frame bit for bit.  Size-independent property (no oracle at
+    this size): a strip is not an approximation of the frame."""
+    import torch
+    W, H, world, spp, prec = 3840, 2160, 8, 16, abi.F16
+    fs = abi.default_settings(spp=spp)
+    with lprt_amd.Renderer(W, H, prec) as full:
+        full.load_scene(sponza)
+        full.enable_counters(True)
+        full.render(fs)
+        b3, e3 = dist.strip_rows(H, world, 3)
+        want = full.read("OUTPUT")[b3:e3].copy()
+        full_rays = {st: full.stage_counters(st)["rays"] for st in ("primary", "trace_gi")}
+    assert (b3, e3) == (810, 1080) and np.isfinite(want).all() and want[..., 3].min() == 1.0
+    ranks = {}
+    for rank in (2, 3, 4):
+        wb, we = dist.window_rows(H, world, rank)
+        b, e = dist.strip_rows(H, world, rank)
+        r = lprt_amd.Renderer(W, H, prec, row_begin=wb, row_end=we)
+        r.load_scene(sponza)
+        r.set_sample_rows(b, e - b)
+        r.enable_counters(True)
+        r.render_phase(fs, abi.PHASE_SAMPLE)
+        ranks[rank] = r
+    assert dist.window_rows(H, world, 3) == (742, 1148)
+    row_bytes = ranks[3].history_row_bytes(abi.HIST_SAMPLES)
+    assert row_bytes == W * 16
+    for src, dst, b, e in dist.history_transfers(H, world):
+        if dst != 3:
+            continue
+        assert src in (2, 4) and e - b == dist.HALO_ROWS
+        buf = torch.empty((e - b) * row_bytes, dtype=torch.uint8, device="cuda")
+        ranks[src].export_history_rows(b, e - b, buf.data_ptr(), abi.HIST_SAMPLES)
+        ranks[src].synchronize()
+        ranks[3].import_history_rows(b, e - b, buf.data_ptr(), abi.HIST_SAMPLES)
+        ranks[3].synchronize()
+    ranks[3].render_phase(fs, abi.PHASE_RESOLVE)
+    got = ranks[3].read("OUTPUT")[b3 - 742:e3 - 742]
+    assert np.array_equal(got, want)
+    # the window traced its primary rays, the samples ran on the owned rows only
+    assert ranks[3].stage_counters("primary")["rays"] == W * (1148 - 742)
+    assert 0 < ranks[3].stage_counters("trace_gi")["rays"] < full_rays["trace_gi"] / 6
+
+
 def test_render_phases_and_sample_rows_are_checked(cornell):
     r = lprt_amd.Renderer(64, 64, abi.F32, row_begin=8, row_end=40)
     r.load_scene(cornell)
@@ -523,12 +628,7 @@ def test_moving_objects_and_camera_reproject_like_the_oracle(cornell, prec):
     r = lprt_amd.Renderer(W, H, prec)
     r.load_scene(cornell)
     for k in range(4):
-        tall = scenes.translate((-0.33, -0.4, -0.3)) @ scenes.rotate_y(17.0 + 6.0 * k) @ scenes.scale((0.6, 1.2, 0.6))
-        short = scenes.translate((0.33 - 0.05 * k, -0.7, 0.3 + 0.03 * k)) @ scenes.rotate_y(-18.0) @ scenes.scale((0.6, 0.6, 0.6))
-        sc = scenes.with_instance_transforms(cornell, {5: tall, 6: short})
-        eye = np.array([0.05 * k, 0.02 * k, 3.5 - 0.1 * k])
-        w2v = scenes.look_at(eye, (0, 0, 0), (0, 1, 0))
-        sc.camera_W2V, sc.camera_L2W = w2v.astype(np.float32), np.linalg.inv(w2v).astype(np.float32)
+        sc = scenes.moving_cornell(k, cornell)
         fs = abi.default_settings(spp=1)
         o.set_scene(sc)
         o.render_frame(fs)
