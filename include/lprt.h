@@ -392,7 +392,17 @@ typedef enum {
     LPRT_OPT_BLAS_LOCAL = 5,       /* 1 (default): subtrees of <= 1024 triangles are ordered in LDS; 0: global passes only.
                                     * LPRT_BLAS_LOCAL */
     LPRT_OPT_DEBUG_SYNC = 6,       /* 1: synchronise and report after every stage.  LPRT_DEBUG_SYNC (set = 1) */
-    LPRT_OPT_COUNT = 7
+    LPRT_OPT_RAY_STREAM = 7,       /* GI and shadow rays as ray streams: persistent waves that refill finished lanes from a
+                                    * work counter (csrc/stream.hpp), the per-pixel stages behind them as kernels of their own.
+                                    * -1 (default): GI rays and the shadow rays of round 1 when some BLAS tree is >= 6 levels
+                                    * deep (large scenes: incoherent rays of very different length; the coherent shadow rays
+                                    * of round 0 keep the fused per-pixel kernel); 0: never; 1: always, round 0 included.
+                                    * lprt_trace_rays follows the same rule.  LPRT_RAY_STREAM */
+    LPRT_OPT_STREAM_WIDE_CLOSEST = 8, /* closest-hit streams walk two BLAS levels per step as well (any-hit streams follow
+                                    * LPRT_OPT_WIDE_WALK).  LPRT_STREAM_WIDE_CLOSEST */
+    LPRT_OPT_STREAM_REFILL_MIN = 9, /* 1..64 (default 48): idle lanes a stream wave collects before it takes new items */
+    LPRT_OPT_STREAM_NODE_MIN = 10,  /* 1..64 (default 20): lanes still descending below which the node loop yields */
+    LPRT_OPT_COUNT = 11
 } lprt_option;
 int lprt_set_option(lprt_ctx *ctx, lprt_option option, int value);
 int lprt_get_option(lprt_ctx *ctx, lprt_option option, int *value);

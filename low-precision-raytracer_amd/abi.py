@@ -91,7 +91,8 @@ STAGE_KERNELS = {"primary": "k_fill_gbuffer", "temporal_map": "k_temporal_map", 
                  "backup": "k_copy_last_transform", "build_tlas": "k_build_tlas"}
 
 # lprt_option, in enum order
-OPTIONS = ["wide_walk", "tlas_mode", "axis_reject", "svgf_always_test", "blas_builder", "blas_local", "debug_sync"]
+OPTIONS = ["wide_walk", "tlas_mode", "axis_reject", "svgf_always_test", "blas_builder", "blas_local", "debug_sync", "ray_stream",
+           "stream_wide_closest", "stream_refill_min", "stream_node_min"]
 RNG_STATE_WORDS = 6
 
 

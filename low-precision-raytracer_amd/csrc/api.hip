@@ -1,6 +1,7 @@
 // C-ABI entry points (include/lprt.h) over the templated renderer implementation.
 #include "build.hpp"
 #include "kernels.hpp"
+#include "stream.hpp"
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -79,7 +80,7 @@ struct CtxBase {
     uint32_t sample_first = 0, sample_rows = 0; // 0 rows: the whole window
     int next_phase = LPRT_PHASE_SAMPLE;
     // behaviour knobs (lprt_option): initialised from the environment once, in lprt_create; never read from it afterwards
-    int opts[LPRT_OPT_COUNT] = {-1, -1, 1, 0, 0, 1, 0};
+    int opts[LPRT_OPT_COUNT] = {-1, -1, 1, 0, 0, 1, 0, -1, 0, 48, 20};
     void options_from_environment() {
         if (const char *w = std::getenv("LPRT_WIDE_WALK"))
             opts[LPRT_OPT_WIDE_WALK] = w[0] == '1' ? 1 : 0;
@@ -95,6 +96,10 @@ struct CtxBase {
             opts[LPRT_OPT_BLAS_LOCAL] = std::string(l) == "0" ? 0 : 1;
         if (std::getenv("LPRT_DEBUG_SYNC"))
             opts[LPRT_OPT_DEBUG_SYNC] = 1;
+        if (const char *r = std::getenv("LPRT_RAY_STREAM"))
+            opts[LPRT_OPT_RAY_STREAM] = r[0] == '1' ? 1 : 0;
+        if (const char *r = std::getenv("LPRT_STREAM_WIDE_CLOSEST"))
+            opts[LPRT_OPT_STREAM_WIDE_CLOSEST] = r[0] == '1' ? 1 : 0;
     }
     // rows [first_row, first_row + n_rows) inside the window?  (the sum in 64 bits: first_row + n_rows may wrap in 32)
     bool rows_inside_window(uint32_t first_row, uint32_t n_rows) const {
@@ -295,6 +300,8 @@ template <typename T> struct Impl : CtxBase {
         fb.prev_frame_count = carve<uint8_t>(off, n);
         fb.last_frame_id = carve<uint2>(off, n);
         fb.output = carve<float4>(off, n);
+        fb.gi_hit = carve<GiHit<T>>(off, n);
+        fb.vis = carve<uint8_t>(off, n * LPRT_MAX_DIRECT_LIGHT);
         off = (off + 255) & ~size_t(255);
     }
     void ensure_frame_buffers() {
@@ -357,6 +364,11 @@ template <typename T> struct Impl : CtxBase {
         return sc;
     }
     // shadow rays walk deep BLAS trees two levels per step (trace.hpp); LPRT_OPT_WIDE_WALK overrides for A/B runs
+    // GI / shadow rays as ray streams (stream.hpp): large scenes by default, LPRT_OPT_RAY_STREAM overrides
+    bool ray_streams() const { return opts[LPRT_OPT_RAY_STREAM] < 0 ? geo.max_depth >= 6 : opts[LPRT_OPT_RAY_STREAM] != 0; }
+    DevBuf d_stream_counters; // one zeroed work counter per stream launch of a frame
+    uint32_t stream_launches = 0;
+    uint32_t *next_stream_counter() { return d_stream_counters.as<uint32_t>() + stream_launches++; }
     bool wide_anyhit() const { return opts[LPRT_OPT_WIDE_WALK] < 0 ? geo.max_depth >= 6 : opts[LPRT_OPT_WIDE_WALK] != 0; }
     uint32_t jitter_d = 0; // d word of this frame's seed A, drawn in the sample phase, used by the temporal maps
     void render_phase(const lprt_frame_settings &fs, int phase) override {
@@ -391,7 +403,16 @@ template <typename T> struct Impl : CtxBase {
         };
         stage(LPRT_STAGE_PRIMARY, [&] { launch_fill_gbuffer<T>(stream, sc, fb, stage_counters(LPRT_STAGE_PRIMARY)); });
         const bool first = frame_index == 0;
-        const bool wide_walk = wide_anyhit();
+        const bool wide_walk = wide_anyhit(), streams = ray_streams(), wide_closest = opts[LPRT_OPT_STREAM_WIDE_CLOSEST] != 0;
+        // round-0 shadow rays start on the camera-visible surface and aim at the same few lights: coherent, and the fused
+        // per-pixel kernel serves them better (atrium: 7.5 vs 12.2 ms per frame) unless streams are forced on
+        const bool stream_round0 = streams && opts[LPRT_OPT_RAY_STREAM] == 1;
+        if (streams) {
+            const size_t need = sizeof(uint32_t) * (3 * (size_t)spp + 1);
+            d_stream_counters.reserve(need);
+            LPRT_HIP(hipMemsetAsync(d_stream_counters.ptr, 0, need, stream));
+            stream_launches = 0;
+        }
         // every curand_init of this frame: seed A of sample 0 (TAA jitter, frames >= 1) over the window + seed B of each
         // sample (shade #1 with GI) over the sample rows -- one batch when the two row ranges coincide.  shade #2 runs with
         // NO_GI and draws nothing (cuda.hpp:1900-1999).
@@ -425,14 +446,28 @@ template <typename T> struct Impl : CtxBase {
             stage(LPRT_STAGE_SHADE1, [&] { launch_shade<T>(stream, sc, sv, !fs.gi_on, d_b, s, reuse); });
             if (!reuse)
                 stage(LPRT_STAGE_TRACE_DI1, [&] {
-                    launch_trace_di<T>(stream, sc, sv, true, fs.gi_on != 0, fs.add_direct_out != 0, s, spp, stage_counters(LPRT_STAGE_TRACE_DI1),
-                                       wide_walk);
+                    if (stream_round0)
+                        launch_stream_di<T>(stream, sc, sv, true, fs.gi_on != 0, fs.add_direct_out != 0, s, spp, next_stream_counter(),
+                                            stage_counters(LPRT_STAGE_TRACE_DI1), wide_walk);
+                    else
+                        launch_trace_di<T>(stream, sc, sv, true, fs.gi_on != 0, fs.add_direct_out != 0, s, spp, stage_counters(LPRT_STAGE_TRACE_DI1),
+                                           wide_walk);
                 });
             if (fs.gi_on) {
                 // trace_gi + shade #2 of the hit in one kernel; trace_di #2 + write_clean_color + spp mean in the next
-                stage(LPRT_STAGE_TRACE_GI, [&] { launch_trace_gi<T>(stream, sc, sv, stage_counters(LPRT_STAGE_TRACE_GI)); });
+                // (ray streams: each of the two as a traversal kernel + a per-pixel kernel)
+                stage(LPRT_STAGE_TRACE_GI, [&] {
+                    if (streams)
+                        launch_stream_gi<T>(stream, sc, sv, next_stream_counter(), stage_counters(LPRT_STAGE_TRACE_GI), wide_closest);
+                    else
+                        launch_trace_gi<T>(stream, sc, sv, stage_counters(LPRT_STAGE_TRACE_GI));
+                });
                 stage(LPRT_STAGE_TRACE_DI2, [&] {
-                    launch_trace_di<T>(stream, sc, sv, false, true, fs.add_direct_out != 0, s, spp, stage_counters(LPRT_STAGE_TRACE_DI2), wide_walk);
+                    if (streams)
+                        launch_stream_di<T>(stream, sc, sv, false, true, fs.add_direct_out != 0, s, spp, next_stream_counter(),
+                                            stage_counters(LPRT_STAGE_TRACE_DI2), wide_walk);
+                    else
+                        launch_trace_di<T>(stream, sc, sv, false, true, fs.add_direct_out != 0, s, spp, stage_counters(LPRT_STAGE_TRACE_DI2), wide_walk);
                 });
             }
         }
@@ -649,6 +684,8 @@ template <typename T> struct Impl : CtxBase {
         if (opts[LPRT_OPT_TLAS_MODE] == 0 || (opts[LPRT_OPT_TLAS_MODE] == 1 && tlas.n_objects <= 32u)) // experiment knob: 0 tree, 1 flat scan
             sc.tlas_mode = (uint32_t)opts[LPRT_OPT_TLAS_MODE];
         sc.axis_reject = opts[LPRT_OPT_AXIS_REJECT] ? 1u : 0u; // A/B switch (results must not depend on it)
+        sc.stream_refill_min = (uint32_t)opts[LPRT_OPT_STREAM_REFILL_MIN];
+        sc.stream_node_min = (uint32_t)opts[LPRT_OPT_STREAM_NODE_MIN];
         sc.objects = d_objects.template as<ObjConst<T>>();
         sc.blas = geo.d_blas.template as<BlasInfo>();
         sc.blas_roots = geo.d_roots.template as<T>();
@@ -692,8 +729,16 @@ template <typename T> struct Impl : CtxBase {
         // the walk the frame kernels would take: any-hit batches follow wide_anyhit(); LPRT_OPT_WIDE_WALK = 1 also sends
         // closest-hit batches through the two-level walk (parity of that walk at hit-record level)
         const bool wide = find_any ? wide_anyhit() : opts[LPRT_OPT_WIDE_WALK] == 1;
-        launch_trace_rays<T>(stream, scene_dev(), d_rays.as<lprt_ray>(), n, find_any != 0, wide, d_hits.as<lprt_hit>(),
-                             stage_counters(LPRT_STAGE_PRIMARY));
+        if (ray_streams()) { // the persistent traversal the frame kernels take in large scenes
+            d_stream_counters.reserve(sizeof(uint32_t) * 4);
+            LPRT_HIP(hipMemsetAsync(d_stream_counters.ptr, 0, sizeof(uint32_t), stream));
+            launch_stream_rays<T>(stream, scene_dev(), d_rays.as<lprt_ray>(), n, find_any != 0,
+                                  find_any ? wide : (wide || opts[LPRT_OPT_STREAM_WIDE_CLOSEST] != 0), d_hits.as<lprt_hit>(),
+                                  d_stream_counters.as<uint32_t>(), stage_counters(LPRT_STAGE_PRIMARY));
+        } else {
+            launch_trace_rays<T>(stream, scene_dev(), d_rays.as<lprt_ray>(), n, find_any != 0, wide, d_hits.as<lprt_hit>(),
+                                 stage_counters(LPRT_STAGE_PRIMARY));
+        }
         LPRT_HIP(hipGetLastError());
         LPRT_HIP(hipMemcpyAsync(hits, d_hits.ptr, sizeof(lprt_hit) * (size_t)n, hipMemcpyDeviceToHost, stream));
         LPRT_HIP(hipStreamSynchronize(stream));
@@ -1120,8 +1165,9 @@ int lprt_set_option(lprt_ctx *ctx, lprt_option option, int value) {
     return guarded(ctx, [&](CtxBase &c) {
         if ((int)option < 0 || (int)option >= LPRT_OPT_COUNT)
             throw std::string("unknown option");
-        const bool tri = option == LPRT_OPT_WIDE_WALK || option == LPRT_OPT_TLAS_MODE; // -1 = automatic
-        if (value > 1 || value < (tri ? -1 : 0))
+        const bool tri = option == LPRT_OPT_WIDE_WALK || option == LPRT_OPT_TLAS_MODE || option == LPRT_OPT_RAY_STREAM; // -1 = automatic
+        const bool lanes = option == LPRT_OPT_STREAM_REFILL_MIN || option == LPRT_OPT_STREAM_NODE_MIN;       // a lane count
+        if (lanes ? (value < 1 || value > 64) : (value > 1 || value < (tri ? -1 : 0)))
             throw std::string("option value out of range");
         c.opts[option] = value;
     });

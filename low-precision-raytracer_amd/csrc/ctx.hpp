@@ -149,6 +149,9 @@ template <typename T> struct FrameDev {
     float4 *output; // RGBA32F
     // RNG: xorwow state planes v0..v4 for the window's pixels (d is uniform per seed)
     uint32_t *rng_state; // [5][npix]
+    // ray streams (stream.hpp): what the persistent traversal kernels leave for the per-pixel stages that follow
+    void *gi_hit;        // GiHit<T>[npix]: the GI ray's intersection, input of shade #2
+    uint8_t *vis;        // [4 slots][npix]: 1 = the shadow ray of that light slot is blocked
 };
 
 } // namespace lprt

