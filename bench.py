@@ -5,10 +5,18 @@
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 A step is one frame of BASELINE.json configs[1]: generated Cornell box, 1920x1080, 4 spp, fp32, GI on, SVGF on,
-TLAS rebuilt per frame as the reference does.  The same run also measures configs[2] (packed fp16) and reports
-it under "fp16".  Inputs (geometry, BVH, materials) are resident in HBM before the timed region starts.
-With N GPUs the frame is cut into N row strips (+ SVGF halo) and completed by one RCCL all-gather per frame
-(lprt_amd.dist); total work is fixed, so scaling is "strong".
+TLAS rebuilt per frame as the reference does.  The same run also measures configs[2] (packed fp16, under "fp16") and, at
+N = 1, configs[3] (the 262 k-triangle atrium, 1080p, 8 spp, fp16, every BLAS rebuilt inside each frame, under "c4" with
+its own roofline and CPU baseline sample).  Inputs (geometry, BVH, materials) are resident in HBM before the timed region
+starts.  With N GPUs the frame is cut into N row strips (+ SVGF halo) and completed by one RCCL all-gather per frame
+(lprt_amd.dist); total work is fixed, so scaling is "strong".  --gpus N > 1 refuses to run unless torch.distributed
+really has N ranks on the nccl (= RCCL) backend: a rehearsal (--rehearsal with --backend gloo / --single-device) is
+labelled as one and carries no value.
+
+`roofline` carries two fractions: `frac` = ALGORITHMIC bytes per launch (visit counters x the reference's record sizes,
+SURVEY.md 8(d)) / launch time / 8 TB/s -- a work rate in the reference's units, which counts cache-resident bytes at
+HBM price -- and `frac_counter` = fabric bytes per launch from the committed rocprofv3 PMC pass of the same workload
+(profiles/pmc_traffic.json) / launch time / 8 TB/s, the measured share of the HBM roof.
 
 Rank 0 prints ONE JSON line.
 """
@@ -170,26 +178,31 @@ def measure(prec, sc, W, H, spp, steps, warmup, rank, world, device, stage_timin
     return res
 
 
-def pmc_traffic(kernel, prec):
-    """HBM bytes per launch of `kernel` from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    separate passes over this same command, FETCH_SIZE doubled as the gfx950 guide prescribes: tools/collect_profiles.sh,
-    tools/summarize_profiles.py).  Counters cannot be read from inside the timed process, so this is the last
-    collected value for the same workload, or None."""
+def workload_key(scene_name, W, H, spp, rebuild_blas):
+    """What a set of PMC counters belongs to: counters of one workload are never attached to another."""
+    return f"{scene_name} {W}x{H} {spp}spp rebuild_blas={int(bool(rebuild_blas))}"
+
+
+def pmc_traffic(kernel, prec, wkey):
+    """Fabric bytes per launch of `kernel` in workload `wkey` from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE in separate passes over the same frames, FETCH_SIZE doubled as the gfx950 guide prescribes:
+    tools/collect_profiles.sh, tools/summarize_profiles.py, tools/merge_pmc.py).  Counters cannot be read from inside the
+    timed process, so this is the last collected value for the SAME workload, or None."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
-        d = json.load(open(path))
+        d = json.load(open(path)).get("workloads", {}).get(wkey, {})
         e = d.get(f"{kernel}[{'f32' if prec == abi.F32 else 'f16'}]")
         if e and "hbm_bytes_per_launch" in e:
-            return e["hbm_bytes_per_launch"], "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+            return e["hbm_bytes_per_launch"], f"profiles/pmc_traffic.json [{wkey}] (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
     except (OSError, ValueError):
         pass
-    return None, None
+    return None, f"no PMC pass committed for [{wkey}]"
 
 
 SAMPLE_STAGES = ("rng", "shade1", "shade2", "compose", "trace_di1", "trace_gi", "trace_di2")  # run on the sample rows only
 
 
-def roofline_of(res, prec, width, spp, world=1):
+def roofline_of(res, prec, width, spp, world, wkey):
     """Dominant kernel family (largest HIP-event time over the calibration frames) against the HBM roof; its launch
     duration is the live average over the timed region, where it is the only instrumented stage."""
     i = 0 if prec == abi.F32 else 1
@@ -204,12 +217,13 @@ def roofline_of(res, prec, width, spp, world=1):
     name, ms, launches = best
     avg_s = ms / launches / 1e3
     npix_window = width * (res["sample_rows"] if name in SAMPLE_STAGES else res["window_rows"][1] - res["window_rows"][0])
+    streams = "shade2" in res["calib"]  # GI / round-1 shadow rays ran as ray streams: their tails are kernels of their own
     if name in RAY_IO:
         per_frame = trace_bytes(res["stage_counters"][name], name, prec)
         launches_per_frame = 1 if name == "primary" else spp
         bytes_per_launch = per_frame / launches_per_frame
         basis = "visit counters x reference record sizes (SURVEY.md 8(d))"
-        if name in FUSED_TAIL:  # the kernel also runs a streaming stage of the reference
+        if name in FUSED_TAIL and not streams:  # the kernel also runs a streaming stage of the reference
             # shade #2 only has work where a GI ray was cast; the composition touches every pixel
             units = res["stage_counters"][name]["rays"] / launches_per_frame if name == "trace_gi" else npix_window
             bytes_per_launch += PIXEL_BYTES[FUSED_TAIL[name]][i] * units
@@ -218,36 +232,60 @@ def roofline_of(res, prec, width, spp, world=1):
         bytes_per_launch = PIXEL_BYTES[name][i] * npix_window
         basis = "compulsory bytes/pixel x pixels (SURVEY.md 8(a))"
     achieved = bytes_per_launch / avg_s
-    kernel = abi.STAGE_KERNELS.get(name, name)
+    kernel = (abi.STREAM_STAGE_KERNELS if streams else {}).get(name) or abi.STAGE_KERNELS.get(name, name)
     # the committed PMC pass is of the N = 1 command: a strip's launches are not comparable
-    traffic, traffic_src = pmc_traffic(kernel, prec) if world == 1 else (None, "collected for N=1 only")
-    return {"bound": "hbm", "kernel": kernel, "stage": name, "achieved": achieved / 1e9,
-            "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
-            "avg_launch_us": avg_s * 1e6, "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
-            "basis": basis}
+    traffic, traffic_src = pmc_traffic(kernel, prec, wkey) if world == 1 else (None, "collected for N=1 only")
+    out = {"bound": "hbm", "kernel": kernel, "stage": name, "achieved": achieved / 1e9,
+           "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
+           "frac_counter": None, "algorithmic_over_traffic": None,
+           "avg_launch_us": avg_s * 1e6, "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
+           "basis": basis,
+           "note": "frac prices every byte a ray touches at the reference's record sizes, cache-resident or not; frac_counter is the "
+                   "measured share of the HBM roof (fabric bytes / launch time / peak). Traversal is bound by dependent fetches and "
+                   "instruction issue, not by either"}
+    if traffic:
+        out["frac_counter"] = traffic / avg_s / HBM_PEAK
+        out["algorithmic_over_traffic"] = bytes_per_launch / traffic
+    return out
 
 
-def cpu_baseline(sc, spp):
+def cpu_baseline(sc, spp, prec=abi.F32, W=1920, H=1080, budget_s=12.0):
     """The CPU oracle (a port of the reference pipeline; the reference has no CPU path) on a bounded sample of the
-    same workload: whole 1080p frames until ~12 s of CPU work have been spent (at most 16 frames)."""
+    same workload: whole frames of W x H until ~budget_s of CPU work have been spent (at most 16 frames).  Mray/s does not
+    depend on the frame size, so the large scene is sampled at a reduced one."""
     from oracle.binding import Oracle
-    W, H = 1920, 1080
     cores = min(len(os.sched_getaffinity(0)), 32)  # the GPU box grants a CPU share; more threads than that only thrash
-    o = Oracle(W, H, abi.F32, threads=cores)
-    o.load_scene(sc)
-    fs = abi.default_settings(spp=spp, gi_on=True, svgf=True)
-    o.reset_counters()
-    frames, t0 = 0, time.perf_counter()
-    while frames < 16 and (frames == 0 or time.perf_counter() - t0 < 12.0):
-        o.set_scene(sc)
-        o.render_frame(fs)
-        frames += 1
-    dt = time.perf_counter() - t0
-    rays = o.counters()["rays"]
-    o.close()
+    with Oracle(W, H, prec, threads=cores) as o:
+        o.load_scene(sc)
+        fs = abi.default_settings(spp=spp, gi_on=True, svgf=True)
+        o.reset_counters()
+        frames, t0 = 0, time.perf_counter()
+        while frames < 16 and (frames == 0 or time.perf_counter() - t0 < budget_s):
+            o.set_scene(sc)
+            o.render_frame(fs)
+            frames += 1
+        dt = time.perf_counter() - t0
+        rays = o.counters()["rays"]
     return {"value": rays / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
-            "sample": f"cornell_box {W}x{H}, {spp} spp, fp32, gi+svgf on, {frames} frame(s), {dt:.1f} s of OpenMP oracle",
+            "sample": f"{sc.name} {W}x{H}, {spp} spp, {'fp32' if prec == abi.F32 else 'fp16'}, gi+svgf on, {frames} frame(s), "
+                      f"{dt:.1f} s of OpenMP oracle (BVH built once, outside the sample)",
             "frames_per_s": frames / dt}
+
+
+def workload_text(sc, W, H, spp, prec, rebuild_blas, reuse_direct):
+    return (f"{sc.name} {W}x{H} {spp}spp {'fp32' if prec == abi.F32 else 'fp16'} gi=on svgf=on traced-primary tlas-per-frame "
+            f"rebuild_blas={int(bool(rebuild_blas))}" + (" reuse_direct_light=1" if reuse_direct else ""))
+
+
+def baseline_config(sc, W, H, spp, prec, rebuild_blas, reuse_direct):
+    """Which BASELINE.json config the arguments of this run are, if any (a label is only attached to the workload it names)."""
+    if reuse_direct or (W, H) != (1920, 1080):
+        return None
+    if sc.name == "cornell" and spp == 4 and not rebuild_blas:
+        return "configs[1]" if prec == abi.F32 else "configs[2]"
+    if sc.name == "sponza_like" and spp == 8 and prec == abi.F16 and rebuild_blas:
+        return "configs[3]"
+    return None
 
 
 def main():
@@ -267,16 +305,21 @@ def main():
                     help="N > 1: every rank also traces its 68 halo rows instead of receiving their sample means from the neighbours")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="nccl (RCCL over xGMI) | gloo (rehearsal: gathers through host memory)")
-    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank renders on GPU 0")
+    ap.add_argument("--backend", default="nccl", help="nccl (RCCL over xGMI) | gloo (needs --rehearsal: gathers through host memory)")
+    ap.add_argument("--single-device", action="store_true", help="needs --rehearsal: every rank renders on GPU 0")
+    ap.add_argument("--rehearsal", action="store_true",
+                    help="N > 1 without N GPUs on RCCL (code-path rehearsal): the JSON line says so and carries value = null")
+    ap.add_argument("--no-c4", action="store_true", help="skip the configs[3] leg (atrium, 8 spp, fp16, BLAS rebuilt per frame)")
     args = ap.parse_args()
 
     rank, world, local = dist_info()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the renderer has no CPU fallback")
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch with torch.distributed.run --nproc-per-node {args.gpus} "
+                         "(no JSON line is printed for a run that is not what it says)")
+    if (args.backend != "nccl" or args.single_device) and not args.rehearsal:
+        raise SystemExit("--backend other than nccl / --single-device are rehearsals of the N > 1 code path, not measurements: pass --rehearsal")
     if args.single_device:
         local = 0
     torch.cuda.set_device(local)
@@ -286,6 +329,11 @@ def main():
             torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             torch.distributed.init_process_group(args.backend)
+        if torch.distributed.get_world_size() != args.gpus or (torch.distributed.get_backend() != "nccl" and not args.rehearsal):
+            raise SystemExit(f"process group has {torch.distributed.get_world_size()} ranks on {torch.distributed.get_backend()}, "
+                             f"not {args.gpus} on nccl")
+        if not args.rehearsal and torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} needs {args.gpus} visible GPUs, found {torch.cuda.device_count()}")
 
     if args.scene in scenes.SCENES:
         sc = scenes.SCENES[args.scene]()
@@ -299,14 +347,22 @@ def main():
                     args.reuse_direct_light, args.trace_halo)
     res16 = None if args.no_fp16 else measure(abi.F16, sc, W, H, spp, args.steps, args.warmup, rank, world, local,
                                                not args.no_stage_timing, args.backend, args.rebuild_blas, args.reuse_direct_light, args.trace_halo)
+    # configs[3] rides along at N = 1 in the default run: the only workload in which traversal of a large scene is the cost
+    res_c4, sc_c4 = None, None
+    if world == 1 and not args.no_c4 and args.scene == "cornell" and (W, H, spp) == (1920, 1080, 4) and not args.rebuild_blas:
+        sc_c4 = scenes.SCENES["sponza_like"]()
+        res_c4 = measure(abi.F16, sc_c4, 1920, 1080, 8, args.steps, args.warmup, rank, world, local, not args.no_stage_timing, args.backend, True,
+                         False, False)
     if rank == 0:
+        wkey = workload_key(sc.name, W, H, spp, args.rebuild_blas)
+        bc32, bc16 = (baseline_config(sc, W, H, spp, p_, args.rebuild_blas, args.reuse_direct_light) for p_ in (abi.F32, abi.F16))
         out = {
             "metric": "Mray/s at 1920x1080, 4 spp (frames/s alongside), fp32 headline + fp16, Cornell-box glTF-equivalent scene",
             "value": res32["mrays_per_s"], "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": res32["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{sc.name} {W}x{H} {spp}spp fp32 gi=on svgf=on traced-primary (BASELINE.json configs[1])",
-                       "triangles": sc.n_tris, "objects": len(sc.objects), "rays_per_frame": res32["frame_rays"],
+            "config": {"workload": workload_text(sc, W, H, spp, abi.F32, args.rebuild_blas, args.reuse_direct_light),
+                       "baseline_config": bc32, "triangles": sc.n_tris, "objects": len(sc.objects), "rays_per_frame": res32["frame_rays"],
                        "parallelism": (f"row-strips x{world} + halo {lp_dist.HALO_ROWS} ({'traced locally' if args.trace_halo else 'samples from the owners'})"
                                        " + all-gather") if world > 1 else "single GPU"},
             "frames_per_s": res32["frames_per_s"],
@@ -318,18 +374,33 @@ def main():
             "stage_ms_note": "3 untimed calibration frames with every stage bracketed by HIP events; the timed region "
                              "instruments the dominant stage only (roofline.avg_launch_us)",
         }
+        if bc32 is None:
+            out["metric"] = f"Mray/s (frames/s alongside) of: {out['config']['workload']} -- NOT a BASELINE.json config"
+        if args.rehearsal:
+            out["rehearsal"] = f"backend={args.backend} single_device={args.single_device}: a rehearsal of the N > 1 code path, not a measurement"
+            out["value_rehearsal"] = out["value"]
+            out["value"] = None
         if res16 is not None:
             out["fp16"] = {"value": res16["mrays_per_s"], "unit": "Mray/s", "ms_per_step": res16["ms_per_step"],
                            "frames_per_s": res16["frames_per_s"], "rays_per_frame": res16["frame_rays"], "dtype": "f16",
-                           "workload": f"{sc.name} {W}x{H} {spp}spp fp16 (BASELINE.json configs[2])",
+                           "workload": workload_text(sc, W, H, spp, abi.F16, args.rebuild_blas, args.reuse_direct_light), "baseline_config": bc16,
                            "speedup_vs_f32": res16["mrays_per_s"] / res32["mrays_per_s"],
                            "stage_ms_per_frame": {k: v[0] for k, v in res16["calib"].items()},
-                           "roofline": roofline_of(res16, abi.F16, W, spp, world) if res16["stage"] else None}
-        out["roofline"] = roofline_of(res32, abi.F32, W, spp, world) if res32["stage"] else None
+                           "roofline": roofline_of(res16, abi.F16, W, spp, world, wkey) if res16["stage"] else None}
+        out["roofline"] = roofline_of(res32, abi.F32, W, spp, world, wkey) if res32["stage"] else None
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sc, spp)
         else:
             out["cpu_baseline"] = None
+        if res_c4 is not None:
+            k4 = workload_key(sc_c4.name, 1920, 1080, 8, True)
+            out["c4"] = {"workload": workload_text(sc_c4, 1920, 1080, 8, abi.F16, True, False), "baseline_config": "configs[3]",
+                         "value": res_c4["mrays_per_s"], "unit": "Mray/s", "dtype": "f16", "ms_per_step": res_c4["ms_per_step"],
+                         "frames_per_s": res_c4["frames_per_s"], "rays_per_frame": res_c4["frame_rays"], "triangles": sc_c4.n_tris,
+                         "build_blas_ms": res_c4["build_blas_ms"], "build_mtris_per_s": sc_c4.n_tris / 1e3 / res_c4["build_blas_ms"],
+                         "output_finite": res_c4["finite"], "stage_ms_per_frame": {k: v[0] for k, v in res_c4["calib"].items()},
+                         "roofline": roofline_of(res_c4, abi.F16, 1920, 8, world, k4) if res_c4["stage"] else None,
+                         "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(sc_c4, 8, abi.F16, 480, 270, budget_s=10.0)}
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()

@@ -214,10 +214,10 @@ typedef enum {
     LPRT_STAGE_RNG = 4,            /* k_rng_expand x3 per seed  (curand_init in the reference's shade) */
     LPRT_STAGE_SHADE1 = 5,         /* k_shade<first>            "Pixel Shade #1" */
     LPRT_STAGE_TRACE_DI1 = 6,      /* k_trace_di<first>         "Trace DI Ray #1" + "Accumulate DI #1" */
-    LPRT_STAGE_TRACE_GI = 7,       /* k_trace_gi                "Trace GI #1" + "Shade #2" of the hit, in registers */
-    LPRT_STAGE_SHADE2 = 8,         /* (runs inside k_trace_gi: no launches of its own) */
+    LPRT_STAGE_TRACE_GI = 7,       /* k_trace_gi ("Trace GI #1" + "Shade #2" of the hit, in registers) or k_stream_gi */
+    LPRT_STAGE_SHADE2 = 8,         /* k_shade2 behind a GI ray stream; inside k_trace_gi otherwise (no launches of its own) */
     LPRT_STAGE_TRACE_DI2 = 9,      /* k_trace_di<second>        "Trace DI #2" + "Accumulate DI #2" + write_clean_color + spp mean */
-    LPRT_STAGE_COMPOSE = 10,       /* (runs inside the last k_trace_di of a sample: no launches of its own) */
+    LPRT_STAGE_COMPOSE = 10,       /* k_accum_di behind a shadow-ray stream; inside the last k_trace_di of a sample otherwise */
     LPRT_STAGE_SVGF_GRADIENT = 11, /* k_depth_gradient */
     LPRT_STAGE_SVGF_TEMPORAL = 12, /* k_temporal_color */
     LPRT_STAGE_SVGF_MOMENTS = 13,  /* k_moments */

@@ -85,8 +85,8 @@ STAGES = ["build_blas", "build_tlas", "primary", "temporal_map", "rng", "shade1"
           "trace_di2", "compose", "svgf_gradient", "svgf_temporal", "svgf_moments", "svgf_wavelet", "finalize", "backup"]
 # device kernel behind each stage id (the names rocprofv3 --kernel-trace reports)
 STAGE_KERNELS = {"primary": "k_fill_gbuffer", "temporal_map": "k_temporal_map", "rng": "k_rng_expand", "shade1": "k_shade",
-                 "trace_di1": "k_trace_di", "trace_gi": "k_trace_gi", "shade2": "k_shade", "trace_di2": "k_trace_di",
-                 "compose": "k_compose", "svgf_gradient": "k_depth_gradient", "svgf_temporal": "k_temporal_color",
+                 "trace_di1": "k_trace_di", "trace_gi": "k_trace_gi", "shade2": "k_shade2", "trace_di2": "k_trace_di",
+                 "compose": "k_accum_di", "svgf_gradient": "k_depth_gradient", "svgf_temporal": "k_temporal_color",
                  "svgf_moments": "k_moments", "svgf_wavelet": "k_wavelet", "finalize": "k_finalize",
                  "backup": "k_copy_last_transform", "build_tlas": "k_build_tlas"}
 
@@ -110,6 +110,9 @@ def expected_abi_info():
                 sizeof_skybox=C.sizeof(Skybox), sizeof_frame_settings=C.sizeof(FrameSettings), sizeof_ray=C.sizeof(Ray),
                 sizeof_hit=C.sizeof(Hit), sizeof_counters=C.sizeof(Counters), rng_state_words=RNG_STATE_WORDS)
 
+
+# the same stages when GI / round-1 shadow rays run as ray streams (large scenes, LPRT_OPT_RAY_STREAM)
+STREAM_STAGE_KERNELS = {"trace_gi": "k_stream_gi", "trace_di2": "k_stream_di"}
 
 # numpy dtypes with identical layout (for bulk ray/hit arrays)
 import numpy as np

@@ -446,29 +446,31 @@ template <typename T> struct Impl : CtxBase {
             stage(LPRT_STAGE_SHADE1, [&] { launch_shade<T>(stream, sc, sv, !fs.gi_on, d_b, s, reuse); });
             if (!reuse)
                 stage(LPRT_STAGE_TRACE_DI1, [&] {
-                    if (stream_round0)
-                        launch_stream_di<T>(stream, sc, sv, true, fs.gi_on != 0, fs.add_direct_out != 0, s, spp, next_stream_counter(),
-                                            stage_counters(LPRT_STAGE_TRACE_DI1), wide_walk);
-                    else
+                    if (stream_round0) {
+                        launch_stream_di<T>(stream, sc, sv, true, next_stream_counter(), stage_counters(LPRT_STAGE_TRACE_DI1), wide_walk);
+                        launch_accum_di<T>(stream, sv, true, fs.gi_on != 0, fs.add_direct_out != 0, s, spp);
+                    } else
                         launch_trace_di<T>(stream, sc, sv, true, fs.gi_on != 0, fs.add_direct_out != 0, s, spp, stage_counters(LPRT_STAGE_TRACE_DI1),
                                            wide_walk);
                 });
             if (fs.gi_on) {
                 // trace_gi + shade #2 of the hit in one kernel; trace_di #2 + write_clean_color + spp mean in the next
                 // (ray streams: each of the two as a traversal kernel + a per-pixel kernel)
-                stage(LPRT_STAGE_TRACE_GI, [&] {
-                    if (streams)
+                if (streams) { // the traversal kernels and the per-pixel kernels behind them are timed as stages of their own
+                    stage(LPRT_STAGE_TRACE_GI, [&] {
                         launch_stream_gi<T>(stream, sc, sv, next_stream_counter(), stage_counters(LPRT_STAGE_TRACE_GI), wide_closest);
-                    else
-                        launch_trace_gi<T>(stream, sc, sv, stage_counters(LPRT_STAGE_TRACE_GI));
-                });
-                stage(LPRT_STAGE_TRACE_DI2, [&] {
-                    if (streams)
-                        launch_stream_di<T>(stream, sc, sv, false, true, fs.add_direct_out != 0, s, spp, next_stream_counter(),
-                                            stage_counters(LPRT_STAGE_TRACE_DI2), wide_walk);
-                    else
+                    });
+                    stage(LPRT_STAGE_SHADE2, [&] { launch_shade2<T>(stream, sc, sv); });
+                    stage(LPRT_STAGE_TRACE_DI2, [&] {
+                        launch_stream_di<T>(stream, sc, sv, false, next_stream_counter(), stage_counters(LPRT_STAGE_TRACE_DI2), wide_walk);
+                    });
+                    stage(LPRT_STAGE_COMPOSE, [&] { launch_accum_di<T>(stream, sv, false, true, fs.add_direct_out != 0, s, spp); });
+                } else {
+                    stage(LPRT_STAGE_TRACE_GI, [&] { launch_trace_gi<T>(stream, sc, sv, stage_counters(LPRT_STAGE_TRACE_GI)); });
+                    stage(LPRT_STAGE_TRACE_DI2, [&] {
                         launch_trace_di<T>(stream, sc, sv, false, true, fs.add_direct_out != 0, s, spp, stage_counters(LPRT_STAGE_TRACE_DI2), wide_walk);
-                });
+                    });
+                }
             }
         }
         LPRT_HIP(hipGetLastError());

@@ -36,12 +36,14 @@ void launch_trace_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &f
 template <typename T> void launch_trace_gi(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, Counters *c);
 
 // ray streams (stream.hpp; kernels in pipeline.hip): persistent waves that refill finished lanes.  `counter` is a zeroed
-// device word owned by this launch.  launch_stream_gi = GI rays + shade #2 of the hits; launch_stream_di = shadow rays +
-// accumulate_di_light (+ write_clean_color and the spp mean in the last round of a sample), as the per-pixel kernels.
+// device word owned by this launch.  launch_stream_gi leaves a hit record per pixel for launch_shade2 (shade #2 of the
+// hits); launch_stream_di leaves a visibility byte per pixel and light slot for launch_accum_di (accumulate_di_light, and
+// in the last round of a sample write_clean_color + the spp mean) -- together what the fused per-pixel kernels do.
 template <typename T> void launch_stream_gi(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t *counter, Counters *c, bool wide);
+template <typename T> void launch_shade2(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb);
 template <typename T>
-void launch_stream_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, bool gi_on, bool add_direct, uint32_t sample, uint32_t spp,
-                      uint32_t *counter, Counters *c, bool wide);
+void launch_stream_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, uint32_t *counter, Counters *c, bool wide);
+template <typename T> void launch_accum_di(hipStream_t st, const FrameDev<T> &fb, bool first, bool gi_on, bool add_direct, uint32_t sample, uint32_t spp);
 template <typename T>
 void launch_stream_rays(hipStream_t st, const SceneDev<T> &sc, const lprt_ray *rays, uint32_t n, bool any, bool wide, lprt_hit *hits, uint32_t *counter,
                         Counters *counters);

@@ -874,6 +874,8 @@ template <typename T, bool WIDE> static void launch_stream_gi_w(hipStream_t st, 
         hipLaunchKernelGGL((k_stream_gi<T, true, WIDE>), stream_grid(k_stream_gi<T, true, WIDE>, n_items), dim3(256), 0, st, sc, fb, n_items, counter, c);
     else
         hipLaunchKernelGGL((k_stream_gi<T, false, WIDE>), stream_grid(k_stream_gi<T, false, WIDE>, n_items), dim3(256), 0, st, sc, fb, n_items, counter, c);
+}
+template <typename T> void launch_shade2(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb) {
     hipLaunchKernelGGL(k_shade2<T>, tile_grid(fb), dim3(256), 0, st, sc, fb);
 }
 template <typename T> void launch_stream_gi(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t *counter, Counters *c, bool wide) {
@@ -896,26 +898,28 @@ static void launch_stream_di_w(hipStream_t st, const SceneDev<T> &sc, const Fram
                            n_items, counter, c);
 }
 template <typename T>
-void launch_stream_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, bool gi_on, bool add_direct, uint32_t sample, uint32_t spp,
-                      uint32_t *counter, Counters *c, bool wide) {
-    const dim3 g = tile_grid(fb), b(256);
-    const ComposeArgs ca{gi_on ? 1 : 0, add_direct ? 1 : 0, sample, spp};
+void launch_stream_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, uint32_t *counter, Counters *c, bool wide) {
     if (first) {
         if (wide)
             launch_stream_di_w<T, true, true>(st, sc, fb, counter, c);
         else
             launch_stream_di_w<T, true, false>(st, sc, fb, counter, c);
-        if (gi_on)
-            hipLaunchKernelGGL((k_accum_di<T, true, false>), g, b, 0, st, fb, ca);
-        else
-            hipLaunchKernelGGL((k_accum_di<T, true, true>), g, b, 0, st, fb, ca);
     } else {
         if (wide)
             launch_stream_di_w<T, false, true>(st, sc, fb, counter, c);
         else
             launch_stream_di_w<T, false, false>(st, sc, fb, counter, c);
-        hipLaunchKernelGGL((k_accum_di<T, false, true>), g, b, 0, st, fb, ca);
     }
+}
+template <typename T> void launch_accum_di(hipStream_t st, const FrameDev<T> &fb, bool first, bool gi_on, bool add_direct, uint32_t sample, uint32_t spp) {
+    const dim3 g = tile_grid(fb), b(256);
+    const ComposeArgs ca{gi_on ? 1 : 0, add_direct ? 1 : 0, sample, spp};
+    if (first && gi_on)
+        hipLaunchKernelGGL((k_accum_di<T, true, false>), g, b, 0, st, fb, ca);
+    else if (first)
+        hipLaunchKernelGGL((k_accum_di<T, true, true>), g, b, 0, st, fb, ca);
+    else
+        hipLaunchKernelGGL((k_accum_di<T, false, true>), g, b, 0, st, fb, ca);
 }
 template <typename T, bool ANY, bool WIDE>
 static void launch_stream_rays_w(hipStream_t st, const SceneDev<T> &sc, const lprt_ray *rays, uint32_t n, lprt_hit *hits, uint32_t *counter, Counters *c) {
@@ -941,7 +945,9 @@ void launch_stream_rays(hipStream_t st, const SceneDev<T> &sc, const lprt_ray *r
 
 #define INST(T)                                                                                                        \
     template void launch_stream_gi<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, uint32_t *, Counters *, bool); \
-    template void launch_stream_di<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, bool, bool, uint32_t, uint32_t, uint32_t *, Counters *, bool); \
+    template void launch_shade2<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &);                             \
+    template void launch_stream_di<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, uint32_t *, Counters *, bool); \
+    template void launch_accum_di<T>(hipStream_t, const FrameDev<T> &, bool, bool, bool, uint32_t, uint32_t);          \
     template void launch_stream_rays<T>(hipStream_t, const SceneDev<T> &, const lprt_ray *, uint32_t, bool, bool, lprt_hit *, uint32_t *, Counters *); \
     template void launch_fill_gbuffer<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, Counters *);          \
     template void launch_temporal_map<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, uint32_t);      \
