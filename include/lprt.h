@@ -169,6 +169,11 @@ typedef struct {
     uint64_t blas_node_visits; /* distinct BLAS nodes whose box was tested */
     uint64_t tri_tests;
     uint64_t fallback_tests;   /* fp32 edge-zone re-tests (cuda.hpp:267-328) */
+    /* lane occupancy of the traversal loops (instrumented kernels only): a wave-step is one pass of a wave through one phase
+     * of the walk, a lane-step one lane taking part in it; lane_steps / (64 * wave_steps) = the share of lanes doing work.
+     * phase 0: instance entry / ray retirement, 1: box tests of a node step, 2: triangle tests at a leaf */
+    uint64_t wave_steps[3];
+    uint64_t lane_steps[3];
 } lprt_counters;
 
 typedef enum {
@@ -400,9 +405,12 @@ typedef enum {
                                     * lprt_trace_rays follows the same rule.  LPRT_RAY_STREAM */
     LPRT_OPT_STREAM_WIDE_CLOSEST = 8, /* closest-hit streams walk two BLAS levels per step as well (any-hit streams follow
                                     * LPRT_OPT_WIDE_WALK).  LPRT_STREAM_WIDE_CLOSEST */
-    LPRT_OPT_STREAM_REFILL_MIN = 9, /* 1..64 (default 48): idle lanes a stream wave collects before it takes new items */
+    LPRT_OPT_STREAM_REFILL_MIN = 9, /* 1..64 (default 12): idle lanes a stream wave collects before it hands out parked rays */
     LPRT_OPT_STREAM_NODE_MIN = 10,  /* 1..64 (default 20): lanes still descending below which the node loop yields */
-    LPRT_OPT_COUNT = 11
+    LPRT_OPT_STREAM_SCHED = 11,     /* 0 (default): a stream wave runs every phase of the walk in every pass; 1: one phase per pass,
+                                     * the one most of its lanes wait for (measured slower: 47.3 vs 44.5 ms on the atrium, the
+                                     * lanes are not waiting for each other's phases but for the stream's tail).  LPRT_STREAM_SCHED */
+    LPRT_OPT_COUNT = 12
 } lprt_option;
 int lprt_set_option(lprt_ctx *ctx, lprt_option option, int value);
 int lprt_get_option(lprt_ctx *ctx, lprt_option option, int *value);

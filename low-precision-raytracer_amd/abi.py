@@ -64,10 +64,13 @@ class Hit(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("rays", "tlas_node_visits", "aabbw_tests", "object_visits",
-                                         "blas_node_visits", "tri_tests", "fallback_tests")]
+                                         "blas_node_visits", "tri_tests", "fallback_tests")] + [("wave_steps", C.c_uint64 * 3),
+                                                                                                ("lane_steps", C.c_uint64 * 3)]
 
     def as_dict(self):
-        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+        d = {n: int(getattr(self, n)) for n, _ in self._fields_[:7]}
+        d["wave_steps"], d["lane_steps"] = [int(v) for v in self.wave_steps], [int(v) for v in self.lane_steps]
+        return d
 
 
 HIST_FILTER, HIST_TAA = 1, 2   # groups of temporal-history planes (include/lprt.h)
@@ -92,7 +95,7 @@ STAGE_KERNELS = {"primary": "k_fill_gbuffer", "temporal_map": "k_temporal_map", 
 
 # lprt_option, in enum order
 OPTIONS = ["wide_walk", "tlas_mode", "axis_reject", "svgf_always_test", "blas_builder", "blas_local", "debug_sync", "ray_stream",
-           "stream_wide_closest", "stream_refill_min", "stream_node_min"]
+           "stream_wide_closest", "stream_refill_min", "stream_node_min", "stream_sched"]
 RNG_STATE_WORDS = 6
 
 

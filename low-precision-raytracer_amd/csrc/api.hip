@@ -80,7 +80,7 @@ struct CtxBase {
     uint32_t sample_first = 0, sample_rows = 0; // 0 rows: the whole window
     int next_phase = LPRT_PHASE_SAMPLE;
     // behaviour knobs (lprt_option): initialised from the environment once, in lprt_create; never read from it afterwards
-    int opts[LPRT_OPT_COUNT] = {-1, -1, 1, 0, 0, 1, 0, -1, 0, 48, 20};
+    int opts[LPRT_OPT_COUNT] = {-1, -1, 1, 0, 0, 1, 0, -1, 0, 12, 20, 0};
     void options_from_environment() {
         if (const char *w = std::getenv("LPRT_WIDE_WALK"))
             opts[LPRT_OPT_WIDE_WALK] = w[0] == '1' ? 1 : 0;
@@ -98,6 +98,8 @@ struct CtxBase {
             opts[LPRT_OPT_DEBUG_SYNC] = 1;
         if (const char *r = std::getenv("LPRT_RAY_STREAM"))
             opts[LPRT_OPT_RAY_STREAM] = r[0] == '1' ? 1 : 0;
+        if (const char *r = std::getenv("LPRT_STREAM_SCHED"))
+            opts[LPRT_OPT_STREAM_SCHED] = r[0] == '1' ? 1 : 0;
         if (const char *r = std::getenv("LPRT_STREAM_WIDE_CLOSEST"))
             opts[LPRT_OPT_STREAM_WIDE_CLOSEST] = r[0] == '1' ? 1 : 0;
     }
@@ -688,6 +690,7 @@ template <typename T> struct Impl : CtxBase {
         sc.axis_reject = opts[LPRT_OPT_AXIS_REJECT] ? 1u : 0u; // A/B switch (results must not depend on it)
         sc.stream_refill_min = (uint32_t)opts[LPRT_OPT_STREAM_REFILL_MIN];
         sc.stream_node_min = (uint32_t)opts[LPRT_OPT_STREAM_NODE_MIN];
+        sc.stream_sched = (uint32_t)opts[LPRT_OPT_STREAM_SCHED];
         sc.objects = d_objects.template as<ObjConst<T>>();
         sc.blas = geo.d_blas.template as<BlasInfo>();
         sc.blas_roots = geo.d_roots.template as<T>();
@@ -761,6 +764,10 @@ template <typename T> struct Impl : CtxBase {
             c.blas_nodes += all[i].blas_nodes;
             c.tris += all[i].tris;
             c.fallbacks += all[i].fallbacks;
+            for (int k = 0; k < 3; k++) {
+                c.wave_steps[k] += all[i].wave_steps[k];
+                c.lane_steps[k] += all[i].lane_steps[k];
+            }
         }
         out->rays = c.rays;
         out->tlas_node_visits = c.tlas_nodes;
@@ -769,6 +776,10 @@ template <typename T> struct Impl : CtxBase {
         out->blas_node_visits = c.blas_nodes;
         out->tri_tests = c.tris;
         out->fallback_tests = c.fallbacks;
+        for (int k = 0; k < 3; k++) {
+            out->wave_steps[k] = c.wave_steps[k];
+            out->lane_steps[k] = c.lane_steps[k];
+        }
     }
     void reset_counters() override { LPRT_HIP(hipMemsetAsync(d_counters.ptr, 0, sizeof(Counters) * LPRT_STAGE_COUNT, stream)); }
     Counters *stage_counters(int stage) { return counters_enabled ? d_counters.as<Counters>() + stage : nullptr; }

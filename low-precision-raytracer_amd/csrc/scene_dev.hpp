@@ -42,7 +42,14 @@ template <typename T> LPRT_DEV void make_objrec(const ObjSlot<T> &slot, const Ob
         r.hi[k] = slot.hi[k];
     }
     r.W2L = oc.W2L;
-    r.pad[0] = r.pad[1] = 0;
+    // pad[0] bit 0: W2L is exactly the identity in DataT -> the instance's rays are the world rays (x*1 + y*0 + z*0 + 0 is exact
+    // and w == 1 skips the division: transform_ray would return the ray unchanged), traversal skips the transform, the
+    // three reciprocals and the 64 bytes of matrix
+    bool ident = true;
+    for (int k = 0; k < 16; k++)
+        ident = ident && oc.W2L.m[k] == ((k % 5 == 0) ? (T)1 : (T)0);
+    r.pad[0] = ident ? 1u : 0u;
+    r.pad[1] = 0;
     r.inscene_objid = slot.inscene_objid;
     r.vao_index = oc.objectid;
     BlasInfo bi{};

@@ -5,9 +5,9 @@
 // lanes active per vector instruction in k_trace_gi / k_trace_di against 97 % in k_shade -- the BVH walk of an incoherent
 // ray is 3-4x longer for the unlucky lane than for the average one.  Here a launch is a STREAM of work items (one per
 // potential ray, numbered so that 64 consecutive items are the rays of one 8x8-pixel block, per light slot for shadow
-// rays) and a fixed set of waves that pull from it: a lane whose ray has finished takes the next item (one atomic add
-// per refill per wave, ballot + prefix count to hand the items out), so the lanes of a wave stay busy until the stream
-// runs dry.  The walk is the same arithmetic as trace.hpp (slab tests, triangle test, culls, skip rule, the one- and
+// rays) and a fixed set of waves that pull from it: a wave takes 64 items at a time (one atomic add), prepares their rays with all of
+// its lanes and parks them in a small LDS ring; a lane whose ray has finished takes the next parked ray (ballot + prefix
+// count), so the lanes of a wave stay busy until the stream runs dry.  The walk is the same arithmetic as trace.hpp (slab tests, triangle test, culls, skip rule, the one- and
 // two-level steps), rewritten as a resumable per-lane state machine:
 //     fetch  ->  [ next candidate instance | TLAS step ]  ->  node steps (while-while)  ->  leaf triangles  ->  ...
 // Results go to planes (visibility byte per light slot, hit record per pixel); the per-pixel stages that used to follow in
@@ -43,12 +43,31 @@ LPRT_DEV bool stream_box(const T *lo, const T *hi, const RaySlab<T> &rs, float b
     return h && tnear < best_t && tnear < max_d && x > min_d;
 }
 
+// A ray made ready for traversal: what the fetch of one item yields (ray, window, skip record, reciprocals) and the result of
+// its world-box scan.  Rays are PREPARED 64 at a time, by all lanes of the wave (the scan of the instances' world boxes is
+// ~30 instructions per box: done by the few lanes that happen to be idle it cost more than the refill saved), parked in a
+// per-wave LDS ring, and handed to lanes as they fall idle -- a pop is a dozen instructions, so a lane waits for work for
+// one iteration of the loop, not until three quarters of the wave have run dry.
+template <typename T> struct PrepRay { // 64 B (f32) / 48 B (f16)
+    V3<T> o, d;
+    T tmin, tmax;
+    uint32_t skip_vao, skip_off, item, cand; // cand: candidate-instance bits (flat scan) or "the TLAS root box is hit" (tree)
+    float ix, iy, iz;
+    uint32_t slow;
+};
+#ifndef LPRT_STREAM_RING
+#define LPRT_STREAM_RING 128u // prepared rays a wave can park (power of two, >= 128: a batch of 64 is prepared when 64 slots are free)
+#endif
+
 // Src: load(item, ray, tmin, tmax, skip_vao, skip_off) -> bool (false: the item carries no ray), store(item, Isect).
 template <typename T, bool ANY, bool COUNT, bool WIDE, typename Src>
 LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items, uint32_t *stream_counter, Cnt<COUNT> &cnt) {
+    __shared__ PrepRay<T> s_ring[4][LPRT_STREAM_RING];
+    PrepRay<T> *ring = s_ring[threadIdx.x >> 6];
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     bool has_ray = false, in_obj = false, exhausted = false;
+    uint32_t head = 0, tail = 0; // ring positions (wave-uniform): [tail, head) are parked
     uint32_t item = 0;
     // world-space ray
     RayT<T> wray{zero3<T>(), zero3<T>()};
@@ -74,63 +93,114 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items, ui
     const bool flat = sc.tlas_mode == 1u;
 
     for (;;) {
-        // ---- fetch: idle lanes take the next items of the stream --------------------------------------------------------
-        const unsigned long long idle = __builtin_amdgcn_ballot_w64(!has_ray);
-        const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle);
-        if (!exhausted && n_idle >= sc.stream_refill_min) { // (SceneDev::stream_refill_min <= 64: a wave of idle lanes always fetches)
+        // ---- prepare: when the ring has room for a batch, all 64 lanes fetch and scan one item each ---------------------
+        if (!exhausted && head - tail <= LPRT_STREAM_RING - 64u) {
             uint32_t base = 0;
-            if (lane == (uint32_t)__builtin_ctzll(idle))
-                base = atomicAdd(stream_counter, n_idle);
-            base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(idle));
-            if (base + n_idle >= n_items)
+            if (lane == 0u)
+                base = atomicAdd(stream_counter, 64u);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (base + 64u >= n_items)
                 exhausted = true; // wave-uniform: nothing is left behind this grant
-            if (!has_ray) {
-                const uint32_t my = base + (uint32_t)__builtin_popcountll(idle & lt_mask);
-                if (my < n_items && src.load(my, wray, tmin, tmax, skip_vao, skip_off)) {
-                    item = my;
+            PrepRay<T> pr;
+            RayT<T> nray{zero3<T>(), zero3<T>()};
+            pr.item = base + lane;
+            const bool ok = pr.item < n_items && src.load(pr.item, nray, pr.tmin, pr.tmax, pr.skip_vao, pr.skip_off);
+            if (ok) {
+                if (COUNT)
+                    cnt.rays++;
+                const RaySlab<T> nrs = make_slab(nray, sc.axis_reject);
+                pr.o = nray.o;
+                pr.d = nray.d;
+                pr.ix = nrs.ix;
+                pr.iy = nrs.iy;
+                pr.iz = nrs.iz;
+                pr.slow = nrs.slow;
+                pr.cand = 0;
+                if (sc.n_objects != 0u) {
+                    if (flat) {
+                        // every world box against the ray (the boxes are wave-uniform addresses: scalar loads)
+                        for (uint32_t k = 0; k < sc.n_objects; k++) {
+                            const ObjRec<T> *ob = sc.objrecs + k;
+                            float a, b;
+                            if (COUNT)
+                                cnt.aabbw++;
+                            if (slab_test_scene(ob->lo, ob->hi, nrs, a, b) && a < (float)pr.tmax && b > (float)pr.tmin)
+                                pr.cand |= 1u << k;
+                        }
+                    } else {
+                        float a, b;
+                        if (COUNT)
+                            cnt.tlas_nodes++;
+                        pr.cand = (slab_test_scene(sc.tlas_root, sc.tlas_root + 3, nrs, a, b) && a < (float)pr.tmax && b > (float)pr.tmin) ? 1u : 0u;
+                    }
+                }
+            }
+            const unsigned long long okm = __builtin_amdgcn_ballot_w64(ok);
+            if (ok)
+                ring[(head + (uint32_t)__builtin_popcountll(okm & lt_mask)) & (LPRT_STREAM_RING - 1u)] = pr;
+            head += (uint32_t)__builtin_popcountll(okm);
+        }
+        // ---- hand out: idle lanes take parked rays ----------------------------------------------------------------------
+        {
+            const unsigned long long idle = __builtin_amdgcn_ballot_w64(!has_ray);
+            const uint32_t avail = head - tail, n_idle = (uint32_t)__builtin_popcountll(idle);
+            if (avail != 0u && (n_idle >= sc.stream_refill_min || n_idle == 64u)) {
+                const uint32_t n_take = avail < n_idle ? avail : n_idle;
+                const uint32_t rank = (uint32_t)__builtin_popcountll(idle & lt_mask);
+                if (!has_ray && rank < n_take) {
+                    const PrepRay<T> pr = ring[(tail + rank) & (LPRT_STREAM_RING - 1u)];
+                    item = pr.item;
+                    wray.o = pr.o;
+                    wray.d = pr.d;
+                    tmin = pr.tmin;
+                    tmax = pr.tmax;
+                    skip_vao = pr.skip_vao;
+                    skip_off = pr.skip_off;
+                    wrs.o = pr.o;
+                    wrs.ix = pr.ix;
+                    wrs.iy = pr.iy;
+                    wrs.iz = pr.iz;
+                    wrs.slow = pr.slow;
+                    wrs.reject = sc.axis_reject;
+                    wrs.par = sc.axis_reject ? pr.slow : 0u;
+                    cand = flat ? pr.cand : 0u;
+                    tlas_live = !flat && pr.cand != 0u;
+                    ti = 1;
+                    tc = 0;
+                    tpend = 0;
+                    tleaf = 0;
                     has_ray = true;
                     in_obj = false;
                     is.hit = false;
                     is.t = cvt<T>(1e5f); // +inf in half (cuda.hpp:54)
                     is.inscene_objid = is.inobject_offset = 0;
                     is.bary = zero3<T>();
-                    if (COUNT)
-                        cnt.rays++;
-                    wrs = make_slab(wray, sc.axis_reject);
-                    cand = 0;
-                    tlas_live = false;
-                    if (sc.n_objects != 0u) {
-                        if (flat) {
-                            // every world box against the ray (the boxes are wave-uniform addresses: scalar loads)
-                            for (uint32_t k = 0; k < sc.n_objects; k++) {
-                                const ObjRec<T> *ob = sc.objrecs + k;
-                                float a, b;
-                                if (COUNT)
-                                    cnt.aabbw++;
-                                if (slab_test_scene(ob->lo, ob->hi, wrs, a, b) && a < (float)tmax && b > (float)tmin)
-                                    cand |= 1u << k;
-                            }
-                        } else {
-                            float a, b;
-                            if (COUNT)
-                                cnt.tlas_nodes++;
-                            tlas_live = slab_test_scene(sc.tlas_root, sc.tlas_root + 3, wrs, a, b) && a < (float)tmax && b > (float)tmin;
-                            ti = 1;
-                            tc = 0;
-                            tpend = 0;
-                            tleaf = 0;
-                        }
-                    }
                 }
+                tail += n_take;
             }
         }
         if (!__builtin_amdgcn_ballot_w64(has_ray)) {
-            if (exhausted)
+            if (exhausted && head == tail)
                 break;
             continue;
         }
+        // ---- which phase runs: the one most lanes are waiting for ---------------------------------------------------------
+        // A lane with a ray is in exactly one of three states: between instances (entry), on an inner node (node), on a leaf
+        // (leaf).  Default (mode 0): all three phases every pass, the node phase repeated while >= stream_node_min lanes descend
+        // ("while-while").  Mode 1 (LPRT_OPT_STREAM_SCHED) runs ONE phase per pass, the one with the most lanes: measured slower
+        // on the atrium (47.3 vs 44.5 ms a frame) at almost unchanged lane occupancy (node 0.47 vs 0.45) -- what keeps the
+        // occupancy at half is not lanes waiting for each other's phase but the stream's tail: a persistent wave gets ~500 rays
+        // and its last ones run 200-400 steps with the lanes of the finished ones empty.
+        const bool majority = sc.stream_sched != 0u;
+        uint32_t n_entry = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(has_ray && !in_obj));
+        uint32_t n_node = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(in_obj && c < D));
+        uint32_t n_leaf = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(in_obj && c == D));
+        const bool run_node = !majority || (n_node >= n_entry && n_node >= n_leaf);
+        const bool run_leaf = !majority || (!run_node && n_leaf >= n_entry);
+        const bool run_entry = !majority || (!run_node && !run_leaf);
         // ---- top level: lanes between instances pick the next candidate, or retire their ray ---------------------------
-        if (has_ray && !in_obj) {
+        if (run_entry && has_ray && !in_obj) {
+            cnt.step(0);
             uint32_t k = 0xffffffffu; // slot of the next instance to enter
             if (!(ANY && is.hit)) {
                 if (flat) {
@@ -188,22 +258,27 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items, ui
                 src.store(item, is); // the ray is done
                 has_ray = false;
             } else {
-                const ObjRec<T> ob = sc.objrecs[k];
+                const ObjRec<T> *ob = sc.objrecs + k; // fields are fetched as they are needed: the matrix only when it is one
                 if (COUNT)
                     cnt.objects++;
-                if (ob.n_tris != 0u) {
-                    lray = transform_ray(wray, ob.W2L);
-                    lrs = make_slab(lray, sc.axis_reject);
+                if (ob->n_tris != 0u) {
+                    if (ob->pad[0] & 1u) { // identity W2L (make_objrec): the instance's ray is the world ray
+                        lray = wray;
+                        lrs = wrs;
+                    } else {
+                        lray = transform_ray(wray, ob->W2L);
+                        lrs = make_slab(lray, sc.axis_reject);
+                    }
                     float tn;
                     if (COUNT)
                         cnt.blas_nodes++;
-                    if (stream_box(ob.root_lo, ob.root_hi, lrs, (float)is.t, (float)tmin, (float)tmax, tn)) {
-                        inner = sc.blas_inner + ob.inner_base;
-                        D = ob.depth;
-                        n_tris = ob.n_tris;
-                        tri_base = ob.tri_base;
-                        obj_id = ob.inscene_objid;
-                        skip_here = ob.vao_index == skip_vao;
+                    if (stream_box(ob->root_lo, ob->root_hi, lrs, (float)is.t, (float)tmin, (float)tmax, tn)) {
+                        inner = sc.blas_inner + ob->inner_base;
+                        D = ob->depth;
+                        n_tris = ob->n_tris;
+                        tri_base = ob->tri_base;
+                        obj_id = ob->inscene_objid;
+                        skip_here = ob->vao_index == skip_vao;
                         i = 1;
                         c = 0;
                         pend = 0;
@@ -224,8 +299,9 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items, ui
             }
         }
         // ---- node steps: "while-while", left early when few lanes are still descending ----------------------------------
-        while (in_obj && c < D) {
+        while (run_node && in_obj && c < D) {
             bool dead = false;
+            cnt.step(1);
             if (WIDE && c + 2u <= D) {
                 const InnerNode<T> ra = inner[2 * i - 1], rb = inner[2 * i];
                 if (COUNT)
@@ -294,12 +370,22 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items, ui
                     c = d;
                 }
             }
-            if ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) < sc.stream_node_min)
+            if (majority) {
+                // stay while the descending lanes are still the largest group (lanes that reached a leaf or left their
+                // instance during this step are counted where they now are)
+                const uint32_t now_node = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(in_obj && c < D));
+                const uint32_t moved = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) - now_node;
+                n_leaf += moved; // upper bound for either of the other groups: cheap, and errs towards leaving early
+                if (now_node < n_leaf || now_node < n_entry + moved)
+                    break;
+            } else if ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) < sc.stream_node_min) {
                 break;
+            }
         }
         // ---- leaf: the wave tests triangles -----------------------------------------------------------------------------
-        if (in_obj && c == D) {
+        if (run_leaf && in_obj && c == D) {
             uint32_t l, r;
+            cnt.step(2);
             leaf_range_dev(i - (1u << D), D, n_tris, l, r);
             for (uint32_t q = l; q < r; q++) {
                 const uint32_t rec = tri_base + q;

@@ -123,6 +123,15 @@ template <typename T> LPRT_DEV bool slab_test_scene(const T *lo, const T *hi, co
 
 template <bool COUNT> struct Cnt {
     unsigned rays = 0, tlas_nodes = 0, aabbw = 0, objects = 0, blas_nodes = 0, tris = 0, fallbacks = 0;
+    unsigned wave_steps[3] = {0, 0, 0}, lane_steps[3] = {0, 0, 0}; // per phase: 0 instance entry, 1 node step, 2 leaf
+    // called by every lane that takes part in a pass through phase `ph`
+    LPRT_DEV void step(int ph) {
+        if (COUNT) {
+            lane_steps[ph]++;
+            if ((threadIdx.x & 63u) == (unsigned)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true)))
+                wave_steps[ph]++;
+        }
+    }
 };
 
 // ---- T3: ray_triangle_intersection (cuda.hpp:193-354) ---------------------------------------------
@@ -249,6 +258,7 @@ LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, const Ray
                             uint32_t skip_off, Isect<T> &is, T min_distance, T max_distance, Cnt<COUNT> &cnt) {
     if (COUNT)
         cnt.objects++;
+    cnt.step(0);
     if (ob.n_tris == 0)
         return;
     float tmn, tmx;
@@ -288,6 +298,7 @@ LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, const Ray
                     const InnerNode<T> ra = inner[2 * i - 1], rb = inner[2 * i];
                     if (COUNT)
                         cnt.blas_nodes += 4;
+                    cnt.step(1);
                     float n[4], x;
                     const float best_t = (float)is.t;
                     bool hh;
@@ -336,6 +347,7 @@ LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, const Ray
             }
             if (!dead) {
                 uint32_t l, r;
+                cnt.step(2);
                 leaf_range_dev(i - (1u << D), D, ob.n_tris, l, r);
                 for (uint32_t k = l; k < r; k++) {
                     uint32_t rec = ob.tri_base + k;
@@ -371,6 +383,7 @@ LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, const Ray
             const InnerNode<T> nd = inner[i - 1];
             if (COUNT)
                 cnt.blas_nodes += 2;
+            cnt.step(1);
             float n0, x0, n1, x1;
             const float best_t = (float)is.t;
             bool h0 = slab_test<T, false, PAR>(nd.lo0, nd.hi0, rs, n0, x0) && n0 < best_t && n0 < max_d && x0 > min_d;
@@ -396,6 +409,7 @@ LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, const Ray
             break;
         {
             uint32_t l, r;
+            cnt.step(2);
             leaf_range_dev(i - (1u << D), D, ob.n_tris, l, r);
             for (uint32_t k = l; k < r; k++) {
                 uint32_t rec = ob.tri_base + k;
@@ -448,10 +462,14 @@ LPRT_DEV Isect<T> cast_ray(const SceneDev<T> &sc, const RayT<T> &ray, uint32_t s
             const uint32_t k = (uint32_t)__builtin_ctz(cand);
             cand &= cand - 1u;
             const ObjRec<T> ob = sc.objrecs[k];
-            // one code path for every instance: with an identity W2L the transform returns the ray unchanged
-            // (x*1 + y*0 + z*0 is exact), and a wave mixing walls and boxes does not run the BLAS walk twice
-            const RayT<T> lr = transform_ray(ray, ob.W2L);
-            const RaySlab<T> lrs = make_slab(lr, sc.axis_reject);
+            // with an identity W2L (ObjRec::pad[0], set by make_objrec) the transform would return the ray unchanged
+            // (x*1 + y*0 + z*0 is exact): the instance is entered with the world ray and its reciprocals as they are
+            RayT<T> lr = ray;
+            RaySlab<T> lrs = rs;
+            if (!(ob.pad[0] & 1u)) {
+                lr = transform_ray(ray, ob.W2L);
+                lrs = make_slab(lr, sc.axis_reject);
+            }
             if (lrs.slow) // rare: the instantiation whose box tests ignore / check the stationary axes
                 traverse_blas<T, ANY, COUNT, true, WIDE>(sc, lr, lrs, ob, skip_vao, skip_off, is, min_distance, max_distance, cnt);
             else
@@ -494,8 +512,12 @@ LPRT_DEV Isect<T> cast_ray(const SceneDev<T> &sc, const RayT<T> &ray, uint32_t s
                     cnt.aabbw++;
                 if (slab_test_scene(ob->lo, ob->hi, rs, tmn, tmx) && tmn < max_d && tmx > min_d) {
                     const ObjRec<T> obv = *ob;
-                    const RayT<T> lr = transform_ray(ray, obv.W2L);
-                    const RaySlab<T> lrs = make_slab(lr, sc.axis_reject);
+                    RayT<T> lr = ray;
+                    RaySlab<T> lrs = rs;
+                    if (!(obv.pad[0] & 1u)) {
+                        lr = transform_ray(ray, obv.W2L);
+                        lrs = make_slab(lr, sc.axis_reject);
+                    }
                     if (lrs.slow)
                         traverse_blas<T, ANY, COUNT, true, WIDE>(sc, lr, lrs, obv, skip_vao, skip_off, is, min_distance, max_distance, cnt);
                     else
@@ -518,10 +540,11 @@ LPRT_DEV Isect<T> cast_ray(const SceneDev<T> &sc, const RayT<T> &ray, uint32_t s
 template <bool COUNT> LPRT_DEV void flush_counters(const Cnt<COUNT> &c, Counters *out) {
     if (!COUNT)
         return;
-    unsigned vals[7] = {c.rays, c.tlas_nodes, c.aabbw, c.objects, c.blas_nodes, c.tris, c.fallbacks};
+    unsigned vals[13] = {c.rays, c.tlas_nodes, c.aabbw, c.objects, c.blas_nodes, c.tris, c.fallbacks, c.wave_steps[0], c.wave_steps[1], c.wave_steps[2],
+                         c.lane_steps[0], c.lane_steps[1], c.lane_steps[2]};
     unsigned long long *dst = reinterpret_cast<unsigned long long *>(out);
 #pragma unroll
-    for (int k = 0; k < 7; k++) {
+    for (int k = 0; k < 13; k++) {
         unsigned v = vals[k];
         for (int off = 32; off > 0; off >>= 1)
             v += __shfl_down(v, off, 64);

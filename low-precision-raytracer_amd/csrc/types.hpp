@@ -90,6 +90,7 @@ template <typename T> struct SceneDev {
     uint32_t tlas_mode;   // 0: tree, 1: flat scan + per-lane candidate list (<= 32 objects)
     uint32_t axis_reject; // 1 (default): trace.hpp's stationary-axis rejection on; 0: the reference's plain slab test
     uint32_t stream_refill_min, stream_node_min; // ray-stream tunables (stream.hpp), lane counts
+    uint32_t stream_sched;                       // 1: one phase per pass, the one most lanes wait for; 0: all phases every pass
     const ObjConst<T> *objects;
     // BLAS
     const BlasInfo *blas;
@@ -175,6 +176,7 @@ template <typename T> struct Isect { // Intersection<DataT>, cuda.hpp:50-57
 
 struct Counters {
     unsigned long long rays, tlas_nodes, aabbw, objects, blas_nodes, tris, fallbacks;
+    unsigned long long wave_steps[3], lane_steps[3]; // lane occupancy per phase of the walk (lprt_counters)
 };
 
 // image window: rows [row_begin, row_end) of a W x H frame (one GPU's strip + halo)

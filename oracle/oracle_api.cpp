@@ -227,6 +227,8 @@ int orc_get_counters(void *p, lprt_counters *out) {
     out->blas_node_visits = c.blas_node_visits;
     out->tri_tests = c.tri_tests;
     out->fallback_tests = c.fallback_tests;
+    for (int k = 0; k < 3; k++)
+        out->wave_steps[k] = out->lane_steps[k] = 0; // GPU-side occupancy counters: no meaning on the CPU
     return 0;
 }
 int orc_reset_counters(void *p) {
