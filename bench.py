@@ -220,16 +220,18 @@ def roofline_of(res, prec, width, spp, world, wkey):
     streams = "shade2" in res["calib"]  # GI / round-1 shadow rays ran as ray streams: their tails are kernels of their own
     if name in RAY_IO:
         per_frame = trace_bytes(res["stage_counters"][name], name, prec)
-        launches_per_frame = 1 if name == "primary" else spp
+        launches_per_frame = max(1, res["calib"][name][1])  # per frame: one per batch of samples (LPRT_OPT_SAMPLE_BATCH), not one per sample
         bytes_per_launch = per_frame / launches_per_frame
         basis = "visit counters x reference record sizes (SURVEY.md 8(d))"
         if name in FUSED_TAIL and not streams:  # the kernel also runs a streaming stage of the reference
             # shade #2 only has work where a GI ray was cast; the composition touches every pixel
-            units = res["stage_counters"][name]["rays"] / launches_per_frame if name == "trace_gi" else npix_window
+            units = res["stage_counters"][name]["rays"] / launches_per_frame if name == "trace_gi" else npix_window * spp / launches_per_frame
             bytes_per_launch += PIXEL_BYTES[FUSED_TAIL[name]][i] * units
             basis += f" + {FUSED_TAIL[name]} compulsory bytes (SURVEY.md 8(a))"
     else:
-        bytes_per_launch = PIXEL_BYTES[name][i] * npix_window
+        per_frame_launches = max(1, res["calib"][name][1]) if name in res["calib"] else 1
+        samples_per_launch = spp / per_frame_launches if name in SAMPLE_STAGES else 1
+        bytes_per_launch = PIXEL_BYTES[name][i] * npix_window * samples_per_launch
         basis = "compulsory bytes/pixel x pixels (SURVEY.md 8(a))"
     achieved = bytes_per_launch / avg_s
     kernel = (abi.STREAM_STAGE_KERNELS if streams else {}).get(name) or abi.STAGE_KERNELS.get(name, name)

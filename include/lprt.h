@@ -410,7 +410,10 @@ typedef enum {
     LPRT_OPT_STREAM_SCHED = 11,     /* 0 (default): a stream wave runs every phase of the walk in every pass; 1: one phase per pass,
                                      * the one most of its lanes wait for (measured slower: 47.3 vs 44.5 ms on the atrium, the
                                      * lanes are not waiting for each other's phases but for the stream's tail).  LPRT_STREAM_SCHED */
-    LPRT_OPT_COUNT = 12
+    LPRT_OPT_SAMPLE_BATCH = 12,     /* 1..8 (default 8): samples of a frame that run through each per-sample stage in one launch
+                                     * (the samples are independent up to the spp mean, which is summed in sample order either way);
+                                     * 1 = one launch per sample and stage, the reference's loop order.  LPRT_SAMPLE_BATCH */
+    LPRT_OPT_COUNT = 13
 } lprt_option;
 int lprt_set_option(lprt_ctx *ctx, lprt_option option, int value);
 int lprt_get_option(lprt_ctx *ctx, lprt_option option, int *value);

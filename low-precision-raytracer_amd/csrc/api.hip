@@ -80,7 +80,7 @@ struct CtxBase {
     uint32_t sample_first = 0, sample_rows = 0; // 0 rows: the whole window
     int next_phase = LPRT_PHASE_SAMPLE;
     // behaviour knobs (lprt_option): initialised from the environment once, in lprt_create; never read from it afterwards
-    int opts[LPRT_OPT_COUNT] = {-1, -1, 1, 0, 0, 1, 0, -1, 0, 12, 20, 0};
+    int opts[LPRT_OPT_COUNT] = {-1, -1, 1, 0, 0, 1, 0, -1, 0, 12, 20, 0, (int)LPRT_MAX_SAMPLE_BATCH};
     void options_from_environment() {
         if (const char *w = std::getenv("LPRT_WIDE_WALK"))
             opts[LPRT_OPT_WIDE_WALK] = w[0] == '1' ? 1 : 0;
@@ -98,6 +98,8 @@ struct CtxBase {
             opts[LPRT_OPT_DEBUG_SYNC] = 1;
         if (const char *r = std::getenv("LPRT_RAY_STREAM"))
             opts[LPRT_OPT_RAY_STREAM] = r[0] == '1' ? 1 : 0;
+        if (const char *r = std::getenv("LPRT_SAMPLE_BATCH"))
+            opts[LPRT_OPT_SAMPLE_BATCH] = std::max(1, std::min((int)LPRT_MAX_SAMPLE_BATCH, std::atoi(r)));
         if (const char *r = std::getenv("LPRT_STREAM_SCHED"))
             opts[LPRT_OPT_STREAM_SCHED] = r[0] == '1' ? 1 : 0;
         if (const char *r = std::getenv("LPRT_STREAM_WIDE_CLOSEST"))
@@ -261,16 +263,6 @@ template <typename T> struct Impl : CtxBase {
         fb.g_color = carve<uint32_t>(off, n);
         fb.g_objid = carve<uint32_t>(off, n);
         fb.g_offset = carve<uint32_t>(off, n);
-        fb.gi_multiplier = carve<V4<T>>(off, n);
-        fb.intensity0 = carve<V4<T>>(off, n);
-        fb.intensity1 = carve<V4<T>>(off, n);
-        fb.skips = carve<uint2>(off, n);
-        fb.gi_direction = carve<V4<T>>(off, n);
-        fb.gi_valid = carve<uint8_t>(off, n);
-        fb.lc_dir_maxt = carve<V4<T>>(off, n * LPRT_MAX_DIRECT_LIGHT);
-        fb.lc_multiplier = carve<V4<T>>(off, n * LPRT_MAX_DIRECT_LIGHT);
-        fb.lc_mask = carve<uint8_t>(off, n);
-        fb.sc_position = carve<V4<T>>(off, n);
         fb.albedo = carve<V4<T>>(off, n);
         fb.color_inprogress = carve<V4<T>>(off, n);
         taa_a = carve<V4<T>>(off, n);
@@ -302,11 +294,52 @@ template <typename T> struct Impl : CtxBase {
         fb.prev_frame_count = carve<uint8_t>(off, n);
         fb.last_frame_id = carve<uint2>(off, n);
         fb.output = carve<float4>(off, n);
-        fb.gi_hit = carve<GiHit<T>>(off, n);
-        fb.vis = carve<uint8_t>(off, n * LPRT_MAX_DIRECT_LIGHT);
         off = (off + 255) & ~size_t(255);
     }
+    // The per-sample planes (FrameDev: sample slots), `slots` of each, in an allocation of their own that grows with the
+    // largest batch a frame has asked for.  Zero-initialised like the arena (thrust::device_vector, cuda.hpp:1599-1608).
+    DevBuf slot_arena;
+    uint32_t slot_capacity = 0, last_slot = 0, last_i0_slot = 0;
+    template <typename U> U *carve_slots(size_t &off, size_t count) {
+        off = (off + 255) & ~size_t(255);
+        U *p = reinterpret_cast<U *>(static_cast<char *>(slot_arena.ptr) + off);
+        off += sizeof(U) * count;
+        return p;
+    }
+    void layout_slots(uint32_t slots, size_t &off) {
+        const size_t n = (size_t)win.npix() * slots;
+        off = 0;
+        fb.smp_stride = win.npix();
+        fb.gi_multiplier = carve_slots<V4<T>>(off, n);
+        fb.intensity0 = carve_slots<V4<T>>(off, n);
+        fb.intensity1 = carve_slots<V4<T>>(off, n);
+        fb.skips = carve_slots<uint2>(off, n);
+        fb.gi_direction = carve_slots<V4<T>>(off, n);
+        fb.gi_valid = carve_slots<uint8_t>(off, n);
+        fb.lc_dir_maxt = carve_slots<V4<T>>(off, n * LPRT_MAX_DIRECT_LIGHT);
+        fb.lc_multiplier = carve_slots<V4<T>>(off, n * LPRT_MAX_DIRECT_LIGHT);
+        fb.lc_mask = carve_slots<uint8_t>(off, n);
+        fb.sc_position = carve_slots<V4<T>>(off, n);
+        fb.gi_hit = carve_slots<GiHit<T>>(off, n);
+        fb.vis = carve_slots<uint8_t>(off, n * LPRT_MAX_DIRECT_LIGHT);
+        fb.smp_color = carve_slots<float4>(off, n);
+        fb.smp_gi_colored = carve_slots<float4>(off, n);
+        fb.smp_gi_white = carve_slots<float4>(off, n);
+        off = (off + 255) & ~size_t(255);
+    }
+    void ensure_sample_slots(uint32_t slots) {
+        if (slots <= slot_capacity)
+            return;
+        size_t total = 0;
+        layout_slots(slots, total); // sizes only (pointers relative to the old / a null allocation)
+        slot_arena.reserve(total);  // contents are scratch of one frame's sample stages: nothing to preserve
+        layout_slots(slots, total);
+        LPRT_HIP(hipMemsetAsync(slot_arena.ptr, 0, total, stream));
+        slot_capacity = slots;
+        last_slot = last_i0_slot = 0;
+    }
     void ensure_frame_buffers() {
+        ensure_sample_slots(1);
         if (arena.ptr)
             return;
         size_t total = 0;
@@ -388,6 +421,9 @@ template <typename T> struct Impl : CtxBase {
         ensure_frame_buffers();
         ensure_last_L2W();
         const uint32_t spp = fs.spp ? fs.spp : 1;
+        // samples per launch of the per-sample stages (LPRT_OPT_SAMPLE_BATCH; FrameDev: sample slots)
+        const uint32_t batch_max = std::min<uint32_t>({spp, (uint32_t)opts[LPRT_OPT_SAMPLE_BATCH], LPRT_MAX_SAMPLE_BATCH});
+        ensure_sample_slots(batch_max);
         if (fs.rebuild_blas) {
             stage(LPRT_STAGE_BUILD_BLAS, [&] { geo.build_blas(stream, opts[LPRT_OPT_BLAS_BUILDER] == 1, opts[LPRT_OPT_BLAS_LOCAL] != 0); });
             objrecs_dirty = true;
@@ -410,7 +446,7 @@ template <typename T> struct Impl : CtxBase {
         // per-pixel kernel serves them better (atrium: 7.5 vs 12.2 ms per frame) unless streams are forced on
         const bool stream_round0 = streams && opts[LPRT_OPT_RAY_STREAM] == 1;
         if (streams) {
-            const size_t need = sizeof(uint32_t) * (3 * (size_t)spp + 1);
+            const size_t need = sizeof(uint32_t) * (3 * (size_t)((spp + batch_max - 1) / batch_max) + 1);
             d_stream_counters.reserve(need);
             LPRT_HIP(hipMemsetAsync(d_stream_counters.ptr, 0, need, stream));
             stream_launches = 0;
@@ -437,44 +473,55 @@ template <typename T> struct Impl : CtxBase {
             });
         }
         jitter_d = first ? 0u : seed_d[0];
-        for (uint32_t s = 0; s < spp; s++) {
-            uint32_t d_b = 0;
+        // opt-in: round 0's light commands and their visibility do not depend on the sample -> cast them for sample 0 only
+        const bool reuse = fs.reuse_direct_light && fs.gi_on;
+        sv.rng_stride = 5 * s_npix;
+        for (uint32_t s0 = 0; s0 < spp; s0 += batch_max) {
+            SampleBatch sb{};
+            sb.first = s0;
+            sb.count = std::min(batch_max, spp - s0);
+            sb.reuse_direct = reuse ? 1u : 0u;
             if (fs.gi_on) {
-                sv.rng_state = d_rng_planes.as<uint32_t>() + b_planes_at + (size_t)s * 5 * s_npix;
-                d_b = seed_d[seeds_a.size() + s];
+                sv.rng_state = d_rng_planes.as<uint32_t>() + b_planes_at + (size_t)s0 * 5 * s_npix;
+                for (uint32_t z = 0; z < sb.count; z++)
+                    sb.rng_d[z] = seed_d[seeds_a.size() + s0 + z];
             }
-            // opt-in: round 0's light commands and their visibility do not depend on the sample -> cast them for sample 0 only
-            const bool reuse = fs.reuse_direct_light && fs.gi_on && s > 0;
-            stage(LPRT_STAGE_SHADE1, [&] { launch_shade<T>(stream, sc, sv, !fs.gi_on, d_b, s, reuse); });
-            if (!reuse)
+            const uint32_t n = sb.count;
+            stage(LPRT_STAGE_SHADE1, [&] { launch_shade<T>(stream, sc, sv, !fs.gi_on, sb); });
+            // round 0's shadow rays: every slot, or (reuse) slot 0 of the batch that holds sample 0
+            const uint32_t n_round0 = !reuse ? n : (s0 == 0 ? 1u : 0u);
+            if (n_round0)
                 stage(LPRT_STAGE_TRACE_DI1, [&] {
                     if (stream_round0) {
-                        launch_stream_di<T>(stream, sc, sv, true, next_stream_counter(), stage_counters(LPRT_STAGE_TRACE_DI1), wide_walk);
-                        launch_accum_di<T>(stream, sv, true, fs.gi_on != 0, fs.add_direct_out != 0, s, spp);
+                        launch_stream_di<T>(stream, sc, sv, true, n_round0, next_stream_counter(), stage_counters(LPRT_STAGE_TRACE_DI1), wide_walk);
+                        launch_accum_di<T>(stream, sv, true, fs.gi_on != 0, fs.add_direct_out != 0, n_round0, reuse);
                     } else
-                        launch_trace_di<T>(stream, sc, sv, true, fs.gi_on != 0, fs.add_direct_out != 0, s, spp, stage_counters(LPRT_STAGE_TRACE_DI1),
-                                           wide_walk);
+                        launch_trace_di<T>(stream, sc, sv, true, fs.gi_on != 0, fs.add_direct_out != 0, n_round0, reuse,
+                                           stage_counters(LPRT_STAGE_TRACE_DI1), wide_walk);
                 });
             if (fs.gi_on) {
-                // trace_gi + shade #2 of the hit in one kernel; trace_di #2 + write_clean_color + spp mean in the next
-                // (ray streams: each of the two as a traversal kernel + a per-pixel kernel)
-                if (streams) { // the traversal kernels and the per-pixel kernels behind them are timed as stages of their own
+                // trace_gi + shade #2 of the hit in one kernel; trace_di #2 + write_clean_color in the next
+                // (ray streams: each of the two as a traversal kernel + a per-pixel kernel, timed as stages of their own)
+                if (streams) {
                     stage(LPRT_STAGE_TRACE_GI, [&] {
-                        launch_stream_gi<T>(stream, sc, sv, next_stream_counter(), stage_counters(LPRT_STAGE_TRACE_GI), wide_closest);
+                        launch_stream_gi<T>(stream, sc, sv, n, next_stream_counter(), stage_counters(LPRT_STAGE_TRACE_GI), wide_closest);
                     });
-                    stage(LPRT_STAGE_SHADE2, [&] { launch_shade2<T>(stream, sc, sv); });
+                    stage(LPRT_STAGE_SHADE2, [&] { launch_shade2<T>(stream, sc, sv, n); });
                     stage(LPRT_STAGE_TRACE_DI2, [&] {
-                        launch_stream_di<T>(stream, sc, sv, false, next_stream_counter(), stage_counters(LPRT_STAGE_TRACE_DI2), wide_walk);
+                        launch_stream_di<T>(stream, sc, sv, false, n, next_stream_counter(), stage_counters(LPRT_STAGE_TRACE_DI2), wide_walk);
                     });
-                    stage(LPRT_STAGE_COMPOSE, [&] { launch_accum_di<T>(stream, sv, false, true, fs.add_direct_out != 0, s, spp); });
+                    stage(LPRT_STAGE_COMPOSE, [&] { launch_accum_di<T>(stream, sv, false, true, fs.add_direct_out != 0, n, reuse); });
                 } else {
-                    stage(LPRT_STAGE_TRACE_GI, [&] { launch_trace_gi<T>(stream, sc, sv, stage_counters(LPRT_STAGE_TRACE_GI)); });
+                    stage(LPRT_STAGE_TRACE_GI, [&] { launch_trace_gi<T>(stream, sc, sv, n, stage_counters(LPRT_STAGE_TRACE_GI)); });
                     stage(LPRT_STAGE_TRACE_DI2, [&] {
-                        launch_trace_di<T>(stream, sc, sv, false, true, fs.add_direct_out != 0, s, spp, stage_counters(LPRT_STAGE_TRACE_DI2), wide_walk);
+                        launch_trace_di<T>(stream, sc, sv, false, true, fs.add_direct_out != 0, n, reuse, stage_counters(LPRT_STAGE_TRACE_DI2), wide_walk);
                     });
                 }
             }
+            stage(LPRT_STAGE_COMPOSE, [&] { launch_spp_mean<T>(stream, sv, sb.first, sb.count, spp); });
+            last_slot = sb.count - 1;
         }
+        last_i0_slot = reuse ? 0u : last_slot;
         LPRT_HIP(hipGetLastError());
     }
     // temporal maps, SVGF, composition with the denoised lobes, TAA, output over the window
@@ -530,8 +577,8 @@ template <typename T> struct Impl : CtxBase {
         case LPRT_BUF_COLOR_INPROGRESS: v4 = fb.color_inprogress; break;
         case LPRT_BUF_MUL_GI_COLORED: v4 = svgf_ran ? fb.lobe[0].cv_c : fb.lobe[0].cv_a; break;
         case LPRT_BUF_MUL_GI_WHITE: v4 = svgf_ran ? fb.lobe[1].cv_c : fb.lobe[1].cv_a; break;
-        case LPRT_BUF_INTENSITY0: v4 = fb.intensity0; break;
-        case LPRT_BUF_INTENSITY1: v4 = fb.intensity1; break;
+        case LPRT_BUF_INTENSITY0: v4 = at_sample(fb, last_i0_slot).intensity0; break; // of the frame's last sample
+        case LPRT_BUF_INTENSITY1: v4 = at_sample(fb, last_slot).intensity1; break;
         case LPRT_BUF_ALBEDO: v4 = fb.albedo; break;
         case LPRT_BUF_RAW_GI_COLORED: v4 = fb.raw_gi_colored; break;
         case LPRT_BUF_RAW_GI_WHITE: v4 = fb.raw_gi_white; break;
@@ -544,11 +591,11 @@ template <typename T> struct Impl : CtxBase {
         case LPRT_BUF_G_OBJID: u32 = fb.g_objid; ch = 1; break;
         case LPRT_BUF_G_OFFSET: u32 = fb.g_offset; ch = 1; break;
         case LPRT_BUF_OUTPUT: ch = 4; break;
-        case LPRT_BUF_GI_DIRECTION: v4 = fb.gi_direction; ch = 4; break;
-        case LPRT_BUF_LIGHT_DIR_MAXT: v4 = fb.lc_dir_maxt; ch = 4; planes = LPRT_MAX_DIRECT_LIGHT; break;
-        case LPRT_BUF_LIGHT_MASK: u8 = fb.lc_mask; ch = 1; break;
-        case LPRT_BUF_SHADE_POSITION: v4 = fb.sc_position; break;
-        case LPRT_BUF_SKIP: u32 = reinterpret_cast<const uint32_t *>(fb.skips); ch = 1; planes = 2; break; // uint2 = two words per pixel
+        case LPRT_BUF_GI_DIRECTION: v4 = at_sample(fb, last_slot).gi_direction; ch = 4; break;
+        case LPRT_BUF_LIGHT_DIR_MAXT: v4 = at_sample(fb, last_slot).lc_dir_maxt; ch = 4; planes = LPRT_MAX_DIRECT_LIGHT; break;
+        case LPRT_BUF_LIGHT_MASK: u8 = at_sample(fb, last_slot).lc_mask; ch = 1; break;
+        case LPRT_BUF_SHADE_POSITION: v4 = at_sample(fb, last_slot).sc_position; break;
+        case LPRT_BUF_SKIP: u32 = reinterpret_cast<const uint32_t *>(at_sample(fb, last_slot).skips); ch = 1; planes = 2; break; // uint2 = two words per pixel
         default: throw std::string("unknown buffer id");
         }
         if ((id == LPRT_BUF_LIGHT_DIR_MAXT || id == LPRT_BUF_LIGHT_MASK) && sample_rows != 0 && sample_rows != win.rows())
@@ -1180,7 +1227,8 @@ int lprt_set_option(lprt_ctx *ctx, lprt_option option, int value) {
             throw std::string("unknown option");
         const bool tri = option == LPRT_OPT_WIDE_WALK || option == LPRT_OPT_TLAS_MODE || option == LPRT_OPT_RAY_STREAM; // -1 = automatic
         const bool lanes = option == LPRT_OPT_STREAM_REFILL_MIN || option == LPRT_OPT_STREAM_NODE_MIN;       // a lane count
-        if (lanes ? (value < 1 || value > 64) : (value > 1 || value < (tri ? -1 : 0)))
+        if (option == LPRT_OPT_SAMPLE_BATCH ? (value < 1 || value > (int)LPRT_MAX_SAMPLE_BATCH)
+                                            : lanes ? (value < 1 || value > 64) : (value > 1 || value < (tri ? -1 : 0)))
             throw std::string("option value out of range");
         c.opts[option] = value;
     });

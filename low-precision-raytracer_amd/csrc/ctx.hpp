@@ -116,6 +116,13 @@ template <typename T> struct TemporalMapT { // TemporalMap<DataT>, cuda.hpp:1055
     uint32_t frame_count;
 };
 
+// what a finished closest-hit ray of a ray stream leaves for the per-pixel stage that follows (k_shade2): Intersection<DataT>, packed
+template <typename T> struct alignas(8) GiHit { // 24 B (f32) / 16 B (f16)
+    uint32_t objid_hit; // bit 31: hit; low bits: inscene_objid
+    uint32_t inobject_offset;
+    T bx, by, bz, t;
+};
+
 // every per-pixel work buffer (RTRTProcedureBuffer<DataT,4>::Ref, cuda.hpp:1538-1561) for the window
 template <typename T> struct FrameDev {
     Window win;
@@ -150,8 +157,39 @@ template <typename T> struct FrameDev {
     // RNG: xorwow state planes v0..v4 for the window's pixels (d is uniform per seed)
     uint32_t *rng_state; // [5][npix]
     // ray streams (stream.hpp): what the persistent traversal kernels leave for the per-pixel stages that follow
-    void *gi_hit;        // GiHit<T>[npix]: the GI ray's intersection, input of shade #2
+    GiHit<T> *gi_hit;    // [npix]: the GI ray's intersection, input of shade #2
     uint8_t *vis;        // [4 slots][npix]: 1 = the shadow ray of that light slot is blocked
+    // Sample slots.  The samples of a frame are independent up to the spp mean, so a BATCH of them runs through each
+    // stage in one launch (gridDim.z / the stream's item range = the samples of the batch): the planes one sample's stages
+    // hand to each other -- gi_multiplier, intensity0/1, skips, gi_direction, gi_valid, the light commands, sc_position,
+    // gi_hit, vis, the RNG states -- exist once per slot; slot z of plane X is X + z * smp_stride elements (the slot-major
+    // light planes and vis: 4 * smp_stride), of the RNG planes rng_state + z * rng_stride.  What write_clean_color
+    // leaves per sample goes to smp_* and k_spp_mean sums the slots in sample order (the float sums of the sample loop,
+    // in the same order).
+    uint32_t smp_stride, rng_stride;
+    float4 *smp_color, *smp_gi_colored, *smp_gi_white;
 };
+#define LPRT_MAX_SAMPLE_BATCH 8u
+// the view of one sample slot
+template <typename T> __host__ __device__ inline FrameDev<T> at_sample(FrameDev<T> f, uint32_t z) {
+    const size_t o = (size_t)z * f.smp_stride;
+    f.gi_multiplier += o;
+    f.intensity0 += o;
+    f.intensity1 += o;
+    f.skips += o;
+    f.gi_direction += o;
+    f.gi_valid += o;
+    f.lc_dir_maxt += o * LPRT_MAX_DIRECT_LIGHT;
+    f.lc_multiplier += o * LPRT_MAX_DIRECT_LIGHT;
+    f.lc_mask += o;
+    f.sc_position += o;
+    f.vis += o * LPRT_MAX_DIRECT_LIGHT;
+    f.gi_hit += o;
+    f.smp_color += o;
+    f.smp_gi_colored += o;
+    f.smp_gi_white += o;
+    f.rng_state += (size_t)z * f.rng_stride;
+    return f;
+}
 
 } // namespace lprt

@@ -25,25 +25,31 @@ void launch_sample_texture(hipStream_t st, const Texture *textures, const float 
 
 
 // pipeline.hip
+// A batch of samples runs through each per-sample stage in ONE launch (FrameDev: sample slots): slot z holds sample first + z.
+struct SampleBatch {
+    uint32_t first, count;                    // count <= LPRT_MAX_SAMPLE_BATCH
+    uint32_t rng_d[LPRT_MAX_SAMPLE_BATCH];    // d word of each slot's shade seed
+    uint32_t reuse_direct;                    // lprt_frame_settings.reuse_direct_light: round 0 runs for sample 0 only
+};
 template <typename T> void launch_fill_gbuffer(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, Counters *c);
 template <typename T> void launch_temporal_map(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, uint32_t rng_d);
+template <typename T> void launch_shade(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool no_gi, const SampleBatch &sb); // round 0; round 1 runs inside k_trace_gi / as k_shade2
 template <typename T>
-void launch_shade(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool no_gi, uint32_t rng_d, uint32_t sample, bool skip_direct); // round 0; round 1 runs inside k_trace_gi
-template <typename T>
-void launch_trace_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, bool gi_on, bool add_direct, uint32_t sample, uint32_t spp,
-                     Counters *c, bool wide); // the last round of a sample also composes (write_clean_color + spp mean);
-                                              // wide: deep BLAS trees, walked two levels per step
-template <typename T> void launch_trace_gi(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, Counters *c);
+void launch_trace_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, bool gi_on, bool add_direct, uint32_t slots, bool reuse,
+                     Counters *c, bool wide); // the last round of a sample also runs write_clean_color; wide: deep BLAS trees, two levels per step
+template <typename T> void launch_trace_gi(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t slots, Counters *c);
+template <typename T> void launch_spp_mean(hipStream_t st, const FrameDev<T> &fb, uint32_t first, uint32_t count, uint32_t spp); // after a batch's last stage
 
 // ray streams (stream.hpp; kernels in pipeline.hip): persistent waves that refill finished lanes.  `counter` is a zeroed
 // device word owned by this launch.  launch_stream_gi leaves a hit record per pixel for launch_shade2 (shade #2 of the
 // hits); launch_stream_di leaves a visibility byte per pixel and light slot for launch_accum_di (accumulate_di_light, and
-// in the last round of a sample write_clean_color + the spp mean) -- together what the fused per-pixel kernels do.
-template <typename T> void launch_stream_gi(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t *counter, Counters *c, bool wide);
-template <typename T> void launch_shade2(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb);
+// in the last round of a sample write_clean_color) -- together what the fused per-pixel kernels do.
 template <typename T>
-void launch_stream_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, uint32_t *counter, Counters *c, bool wide);
-template <typename T> void launch_accum_di(hipStream_t st, const FrameDev<T> &fb, bool first, bool gi_on, bool add_direct, uint32_t sample, uint32_t spp);
+void launch_stream_gi(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t slots, uint32_t *counter, Counters *c, bool wide);
+template <typename T> void launch_shade2(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t slots);
+template <typename T>
+void launch_stream_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, uint32_t slots, uint32_t *counter, Counters *c, bool wide);
+template <typename T> void launch_accum_di(hipStream_t st, const FrameDev<T> &fb, bool first, bool gi_on, bool add_direct, uint32_t slots, bool reuse);
 template <typename T>
 void launch_stream_rays(hipStream_t st, const SceneDev<T> &sc, const lprt_ray *rays, uint32_t n, bool any, bool wide, lprt_hit *hits, uint32_t *counter,
                         Counters *counters);

@@ -459,7 +459,10 @@ LPRT_DEV void shade_and_store(const SceneDev<T> &sc, const FrameDev<T> &fb, uint
 }
 
 template <typename T, bool NO_GI>
-__global__ void __launch_bounds__(256) k_shade(SceneDev<T> sc, FrameDev<T> fb, uint32_t rng_d, uint32_t sample, uint32_t skip_direct) {
+__global__ void __launch_bounds__(256) k_shade(SceneDev<T> sc, FrameDev<T> fb0, SampleBatch sa) {
+    const FrameDev<T> fb = at_sample(fb0, blockIdx.z);
+    const uint32_t sample = sa.first + blockIdx.z, rng_d = sa.rng_d[blockIdx.z];
+    const uint32_t skip_direct = (sa.reuse_direct && sample > 0u) ? 1u : 0u;
     const uint32_t p = tile_pixel(fb);
     if (p >= fb.win.npix())
         return;
@@ -494,15 +497,17 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev<T> sc, FrameDev<T> fb, u
 // sample s of n accumulates in f32 in sample order; the last sample divides once and rounds once to DataT.
 struct ComposeArgs {
     int gi_on, add_direct_out;
-    uint32_t sample, spp;
+    uint32_t reuse_direct; // round 0 ran for sample 0 only (lprt_frame_settings.reuse_direct_light): its radiance is slot 0's
 };
-// write_clean_color + the spp mean for pixel p, whose radiance of this round (`cur`) has just been completed
-template <typename T, bool FIRST> LPRT_DEV void compose_tail(const FrameDev<T> &fb, const ComposeArgs &ca, uint32_t p, V4<T> cur) {
-    const T zero = (T)0;
+// write_clean_color (cuda.hpp:2170-2199) for pixel p of one sample slot, whose radiance of this round (`cur`) has just been
+// completed: the sample's three contributions go to the slot's smp_* planes (f32) and k_spp_mean sums the slots in sample
+// order.  slot0: the frame planes of slot 0 (round 0's radiance under reuse_direct_light).
+template <typename T, bool FIRST>
+LPRT_DEV void compose_tail(const FrameDev<T> &fb, const FrameDev<T> &slot0, const ComposeArgs &ca, uint32_t p, V4<T> cur) {
     V3<T> fc = zero3<T>(), colored = zero3<T>(), white = zero3<T>();
     const V4<T> m0 = fb.gi_multiplier[p];
     if (ca.add_direct_out)
-        fc = FIRST ? xyz(cur) : xyz(fb.intensity0[p]);
+        fc = FIRST ? xyz(cur) : xyz((ca.reuse_direct ? slot0.intensity0 : fb.intensity0)[p]);
     const V3<T> i1 = FIRST ? zero3<T>() : xyz(cur); // gi off: there is no second round
     if (tisnan(m0.z)) {
         colored = m0.x * i1;
@@ -510,26 +515,45 @@ template <typename T, bool FIRST> LPRT_DEV void compose_tail(const FrameDev<T> &
     } else if (ca.add_direct_out) {
         fc = fc + elemul(i1, xyz(m0));
     }
-    float4 ac = make_float4((float)fc.x, (float)fc.y, (float)fc.z, 0.f);
-    float4 ag = make_float4((float)colored.x, (float)colored.y, (float)colored.z, 0.f);
-    float4 aw = make_float4((float)white.x, (float)white.y, (float)white.z, 0.f);
-    if (ca.sample > 0) {
-        float4 o = fb.acc_color[p];
-        ac = make_float4(o.x + ac.x, o.y + ac.y, o.z + ac.z, 0.f);
-        o = fb.acc_gi_colored[p];
-        ag = make_float4(o.x + ag.x, o.y + ag.y, o.z + ag.z, 0.f);
-        o = fb.acc_gi_white[p];
-        aw = make_float4(o.x + aw.x, o.y + aw.y, o.z + aw.z, 0.f);
+    fb.smp_color[p] = make_float4((float)fc.x, (float)fc.y, (float)fc.z, 0.f);
+    fb.smp_gi_colored[p] = make_float4((float)colored.x, (float)colored.y, (float)colored.z, 0.f);
+    fb.smp_gi_white[p] = make_float4((float)white.x, (float)white.y, (float)white.z, 0.f);
+}
+// The build-side spp mean: sample s of n accumulates in f32 in sample order; the last sample divides once and rounds once to
+// DataT (spp = 1 is exactly a reference frame).  One launch per batch of samples, after the batch's last stage.
+template <typename T> __global__ void __launch_bounds__(256) k_spp_mean(FrameDev<T> fb, uint32_t first, uint32_t count, uint32_t spp) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= fb.win.npix())
+        return;
+    const T zero = (T)0;
+    float4 ac = make_float4(0.f, 0.f, 0.f, 0.f), ag = ac, aw = ac;
+    for (uint32_t z = 0; z < count; z++) {
+        const size_t q = (size_t)z * fb.smp_stride + p;
+        const float4 c = fb.smp_color[q], g = fb.smp_gi_colored[q], w = fb.smp_gi_white[q];
+        if (first + z == 0u) {
+            ac = c;
+            ag = g;
+            aw = w;
+        } else {
+            if (z == 0u) {
+                ac = fb.acc_color[p];
+                ag = fb.acc_gi_colored[p];
+                aw = fb.acc_gi_white[p];
+            }
+            ac = make_float4(ac.x + c.x, ac.y + c.y, ac.z + c.z, 0.f);
+            ag = make_float4(ag.x + g.x, ag.y + g.y, ag.z + g.z, 0.f);
+            aw = make_float4(aw.x + w.x, aw.y + w.y, aw.z + w.z, 0.f);
+        }
     }
-    if (ca.sample + 1 < ca.spp) {
+    if (first + count < spp) {
         fb.acc_color[p] = ac;
         fb.acc_gi_colored[p] = ag;
         fb.acc_gi_white[p] = aw;
     } else {
-        const float n = (float)ca.spp;
-        V4<T> c = mk4(cvt<T>(ac.x / n), cvt<T>(ac.y / n), cvt<T>(ac.z / n), zero);
-        V4<T> g = mk4(cvt<T>(ag.x / n), cvt<T>(ag.y / n), cvt<T>(ag.z / n), zero);
-        V4<T> w = mk4(cvt<T>(aw.x / n), cvt<T>(aw.y / n), cvt<T>(aw.z / n), zero);
+        const float n = (float)spp;
+        const V4<T> c = mk4(cvt<T>(ac.x / n), cvt<T>(ac.y / n), cvt<T>(ac.z / n), zero);
+        const V4<T> g = mk4(cvt<T>(ag.x / n), cvt<T>(ag.y / n), cvt<T>(ag.z / n), zero);
+        const V4<T> w = mk4(cvt<T>(aw.x / n), cvt<T>(aw.y / n), cvt<T>(aw.z / n), zero);
         fb.color_inprogress[p] = c;
         fb.lobe[0].cv_a[p] = g;
         fb.lobe[1].cv_a[p] = w;
@@ -539,7 +563,8 @@ template <typename T, bool FIRST> LPRT_DEV void compose_tail(const FrameDev<T> &
     }
 }
 template <typename T, bool FIRST, bool COMPOSE, bool COUNT, bool WIDE>
-__global__ void __launch_bounds__(256, LPRT_ANYHIT_WAVES) k_trace_di(SceneDev<T> sc, FrameDev<T> fb, ComposeArgs ca, Counters *counters) {
+__global__ void __launch_bounds__(256, LPRT_ANYHIT_WAVES) k_trace_di(SceneDev<T> sc, FrameDev<T> fb0, ComposeArgs ca, Counters *counters) {
+    const FrameDev<T> fb = at_sample(fb0, blockIdx.z);
     const uint32_t p = tile_pixel(fb);
     const uint32_t npix = fb.win.npix();
     Cnt<COUNT> cnt;
@@ -567,7 +592,7 @@ __global__ void __launch_bounds__(256, LPRT_ANYHIT_WAVES) k_trace_di(SceneDev<T>
             intensity[p] = cur;
         }
         if (COMPOSE)
-            compose_tail<T, FIRST>(fb, ca, p, cur);
+            compose_tail<T, FIRST>(fb, fb0, ca, p, cur);
     }
     flush_counters<COUNT>(cnt, counters);
 }
@@ -605,7 +630,8 @@ template <typename T> LPRT_DEV void shade_gi_hit(const SceneDev<T> &sc, const Fr
 }
 
 template <typename T, bool COUNT>
-__global__ void __launch_bounds__(256, LPRT_CLOSEST_WAVES) k_trace_gi(SceneDev<T> sc, FrameDev<T> fb, Counters *counters) {
+__global__ void __launch_bounds__(256, LPRT_CLOSEST_WAVES) k_trace_gi(SceneDev<T> sc, FrameDev<T> fb0, Counters *counters) {
+    const FrameDev<T> fb = at_sample(fb0, blockIdx.z);
     uint32_t p = tile_pixel(fb);
     {
         uint32_t key = 8u; // no GI ray
@@ -630,6 +656,8 @@ __global__ void __launch_bounds__(256, LPRT_CLOSEST_WAVES) k_trace_gi(SceneDev<T
     flush_counters<COUNT>(cnt, counters);
 }
 
+static inline dim3 grid_for(uint32_t n) { return dim3((n + 255) / 256); }
+
 // ---- ray streams (stream.hpp): persistent traversal kernels + the per-pixel stages that follow them ----------------------
 #ifndef LPRT_STREAM_WAVES
 #define LPRT_STREAM_WAVES 4 // waves per SIMD the stream kernels are compiled for
@@ -643,10 +671,13 @@ template <typename T> LPRT_DEV uint32_t block_pixel(const FrameDev<T> &fb, uint3
 }
 template <typename T> static inline uint32_t n_blocks8(const FrameDev<T> &fb) { return ((fb.win.W + 7u) / 8u) * ((fb.win.rows() + 7u) / 8u); }
 
-template <typename T> struct GiSource { // trace_gi's rays (cuda.hpp:2083-2105): one item per pixel
-    FrameDev<T> fb;
+template <typename T> struct GiSource { // trace_gi's rays (cuda.hpp:2083-2105): one item per pixel and sample slot
+    FrameDev<T> fb0;
+    uint32_t per_slot; // items of one sample slot
     LPRT_DEV bool load(uint32_t item, RayT<T> &ray, T &tmin, T &tmax, uint32_t &skip_vao, uint32_t &skip_off) const {
-        const uint32_t p = block_pixel(fb, item >> 6, item & 63u);
+        const uint32_t z = item / per_slot, it = item - z * per_slot;
+        const FrameDev<T> fb = at_sample(fb0, z);
+        const uint32_t p = block_pixel(fb, it >> 6, it & 63u);
         if (p == 0xffffffffu || !fb.gi_valid[p])
             return false;
         const uint2 skip = fb.skips[p];
@@ -659,7 +690,9 @@ template <typename T> struct GiSource { // trace_gi's rays (cuda.hpp:2083-2105):
         return true;
     }
     LPRT_DEV void store(uint32_t item, const Isect<T> &is) const {
-        const uint32_t p = block_pixel(fb, item >> 6, item & 63u);
+        const uint32_t z = item / per_slot, it = item - z * per_slot;
+        const FrameDev<T> fb = at_sample(fb0, z);
+        const uint32_t p = block_pixel(fb, it >> 6, it & 63u);
         GiHit<T> h;
         h.objid_hit = (is.hit ? 0x80000000u : 0u) | is.inscene_objid;
         h.inobject_offset = is.inobject_offset;
@@ -667,20 +700,24 @@ template <typename T> struct GiSource { // trace_gi's rays (cuda.hpp:2083-2105):
         h.by = is.bary.y;
         h.bz = is.bary.z;
         h.t = is.t;
-        static_cast<GiHit<T> *>(fb.gi_hit)[p] = h;
+        fb.gi_hit[p] = h;
     }
 };
-template <typename T, bool FIRST> struct DiSource { // trace_di_light's rays (cuda.hpp:2058-2081): one item per pixel and light slot
-    FrameDev<T> fb;
-    uint32_t n_slots; // min(n_lights, 4): items of one 8x8 block = n_slots runs of 64, slot-major (a wave's rays aim at one light)
-    LPRT_DEV void where(uint32_t item, uint32_t &p, uint32_t &slot) const {
-        const uint32_t run = item >> 6;
+template <typename T, bool FIRST> struct DiSource { // trace_di_light's rays (cuda.hpp:2058-2081): one item per pixel, light slot and sample slot
+    FrameDev<T> fb0;
+    uint32_t n_slots;  // min(n_lights, 4): items of one 8x8 block = n_slots runs of 64, slot-major (a wave's rays aim at one light)
+    uint32_t per_slot; // items of one sample slot
+    LPRT_DEV FrameDev<T> where(uint32_t item, uint32_t &p, uint32_t &slot) const {
+        const uint32_t z = item / per_slot, it = item - z * per_slot;
+        const FrameDev<T> fb = at_sample(fb0, z);
+        const uint32_t run = it >> 6;
         slot = run % n_slots;
-        p = block_pixel(fb, run / n_slots, item & 63u);
+        p = block_pixel(fb, run / n_slots, it & 63u);
+        return fb;
     }
     LPRT_DEV bool load(uint32_t item, RayT<T> &ray, T &tmin, T &tmax, uint32_t &skip_vao, uint32_t &skip_off) const {
         uint32_t p, slot;
-        where(item, p, slot);
+        const FrameDev<T> fb = where(item, p, slot);
         if (p == 0xffffffffu || !((fb.lc_mask[p] >> slot) & 1u))
             return false;
         const uint32_t npix = fb.win.npix();
@@ -696,7 +733,7 @@ template <typename T, bool FIRST> struct DiSource { // trace_di_light's rays (cu
     }
     LPRT_DEV void store(uint32_t item, const Isect<T> &is) const {
         uint32_t p, slot;
-        where(item, p, slot);
+        const FrameDev<T> fb = where(item, p, slot);
         fb.vis[slot * fb.win.npix() + p] = is.hit ? 1u : 0u;
     }
 };
@@ -727,17 +764,18 @@ template <typename T> struct HostRaySource { // lprt_trace_rays
 };
 
 template <typename T, bool COUNT, bool WIDE>
-__global__ void __launch_bounds__(256, LPRT_STREAM_WAVES) k_stream_gi(SceneDev<T> sc, FrameDev<T> fb, uint32_t n_items, uint32_t *counter, Counters *counters) {
+__global__ void __launch_bounds__(256, LPRT_STREAM_WAVES) k_stream_gi(SceneDev<T> sc, FrameDev<T> fb, uint32_t per_slot, uint32_t n_items, uint32_t *counter,
+                                                                       Counters *counters) {
     Cnt<COUNT> cnt;
-    GiSource<T> src{fb};
+    GiSource<T> src{fb, per_slot};
     trace_stream<T, false, COUNT, WIDE>(sc, src, n_items, counter, cnt);
     flush_counters<COUNT>(cnt, counters);
 }
 template <typename T, bool FIRST, bool COUNT, bool WIDE>
-__global__ void __launch_bounds__(256, LPRT_STREAM_WAVES) k_stream_di(SceneDev<T> sc, FrameDev<T> fb, uint32_t n_slots, uint32_t n_items, uint32_t *counter,
-                                                                       Counters *counters) {
+__global__ void __launch_bounds__(256, LPRT_STREAM_WAVES) k_stream_di(SceneDev<T> sc, FrameDev<T> fb, uint32_t n_slots, uint32_t per_slot, uint32_t n_items,
+                                                                       uint32_t *counter, Counters *counters) {
     Cnt<COUNT> cnt;
-    DiSource<T, FIRST> src{fb, n_slots};
+    DiSource<T, FIRST> src{fb, n_slots, per_slot};
     trace_stream<T, true, COUNT, WIDE>(sc, src, n_items, counter, cnt);
     flush_counters<COUNT>(cnt, counters);
 }
@@ -751,7 +789,8 @@ __global__ void __launch_bounds__(256, LPRT_STREAM_WAVES) k_stream_rays(SceneDev
 }
 
 // shade #2 of every pixel on the hit record its GI ray left (the tail of k_trace_gi as a kernel of its own)
-template <typename T> __global__ void __launch_bounds__(256) k_shade2(SceneDev<T> sc, FrameDev<T> fb) {
+template <typename T> __global__ void __launch_bounds__(256) k_shade2(SceneDev<T> sc, FrameDev<T> fb0) {
+    const FrameDev<T> fb = at_sample(fb0, blockIdx.z);
     const uint32_t p = tile_pixel(fb);
     if (p >= fb.win.npix())
         return;
@@ -759,7 +798,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_shade2(SceneDev<T
     Isect<T> is;
     is.hit = false;
     if (cast) {
-        const GiHit<T> h = static_cast<const GiHit<T> *>(fb.gi_hit)[p];
+        const GiHit<T> h = fb.gi_hit[p];
         is.hit = (h.objid_hit >> 31) != 0u;
         is.inscene_objid = h.objid_hit & 0x7fffffffu;
         is.inobject_offset = h.inobject_offset;
@@ -770,7 +809,8 @@ template <typename T> __global__ void __launch_bounds__(256) k_shade2(SceneDev<T
 }
 // accumulate_di_light over the visibility bytes the shadow-ray stream left (the tail of k_trace_di as a kernel of its own)
 template <typename T, bool FIRST, bool COMPOSE>
-__global__ void __launch_bounds__(256) k_accum_di(FrameDev<T> fb, ComposeArgs ca) {
+__global__ void __launch_bounds__(256) k_accum_di(FrameDev<T> fb0, ComposeArgs ca) {
+    const FrameDev<T> fb = at_sample(fb0, blockIdx.z);
     const uint32_t p = tile_pixel(fb);
     const uint32_t npix = fb.win.npix();
     if (p >= npix)
@@ -791,7 +831,7 @@ __global__ void __launch_bounds__(256) k_accum_di(FrameDev<T> fb, ComposeArgs ca
         intensity[p] = cur;
     }
     if (COMPOSE)
-        compose_tail<T, FIRST>(fb, ca, p, cur);
+        compose_tail<T, FIRST>(fb, fb0, ca, p, cur);
 }
 
 // persistent grid: as many workgroups as the chip holds at once (occupancy x CUs), never more than the stream has work for
@@ -811,7 +851,6 @@ template <typename K> static dim3 stream_grid(K kernel, uint32_t n_items) {
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------
-static inline dim3 grid_for(uint32_t n) { return dim3((n + 255) / 256); }
 
 template <typename T> void launch_fill_gbuffer(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, Counters *c) {
     if (c)
@@ -822,20 +861,22 @@ template <typename T> void launch_fill_gbuffer(hipStream_t st, const SceneDev<T>
 template <typename T> void launch_temporal_map(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, uint32_t rng_d) {
     hipLaunchKernelGGL(k_temporal_map<T>, grid_for(fb.win.npix()), dim3(256), 0, st, sc, fb, first ? 1 : 0, rng_d);
 }
-template <typename T>
-void launch_shade(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool no_gi, uint32_t rng_d, uint32_t sample, bool skip_direct) {
-    dim3 g = tile_grid(fb), b(256);
+// tiles x sample slots of the batch
+template <typename T> static inline dim3 tile_grid_z(const FrameDev<T> &fb, uint32_t slots) { return dim3(tile_grid(fb).x, 1, slots); }
+
+template <typename T> void launch_shade(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool no_gi, const SampleBatch &sb) {
+    const dim3 g = tile_grid_z(fb, sb.count), b(256);
     if (!no_gi)
-        hipLaunchKernelGGL((k_shade<T, false>), g, b, 0, st, sc, fb, rng_d, sample, skip_direct ? 1u : 0u);
+        hipLaunchKernelGGL((k_shade<T, false>), g, b, 0, st, sc, fb, sb);
     else
-        hipLaunchKernelGGL((k_shade<T, true>), g, b, 0, st, sc, fb, rng_d, sample, skip_direct ? 1u : 0u);
+        hipLaunchKernelGGL((k_shade<T, true>), g, b, 0, st, sc, fb, sb);
 }
 // wide: the BLAS set holds deep trees (GeometryStore::max_depth >= 6): the shadow rays walk them two levels per step
 template <typename T, bool WIDE>
-static void launch_trace_di_w(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, bool gi_on, bool add_direct, uint32_t sample,
-                              uint32_t spp, Counters *c) {
-    dim3 g = tile_grid(fb), b(256);
-    ComposeArgs ca{gi_on ? 1 : 0, add_direct ? 1 : 0, sample, spp};
+static void launch_trace_di_w(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, bool gi_on, bool add_direct, uint32_t slots,
+                              uint32_t reuse, Counters *c) {
+    const dim3 g = tile_grid_z(fb, slots), b(256);
+    const ComposeArgs ca{gi_on ? 1 : 0, add_direct ? 1 : 0, reuse};
     if (first && gi_on) {
         if (c)
             hipLaunchKernelGGL((k_trace_di<T, true, false, true, WIDE>), g, b, 0, st, sc, fb, ca, c);
@@ -854,66 +895,72 @@ static void launch_trace_di_w(hipStream_t st, const SceneDev<T> &sc, const Frame
     }
 }
 template <typename T>
-void launch_trace_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, bool gi_on, bool add_direct, uint32_t sample, uint32_t spp,
+void launch_trace_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, bool gi_on, bool add_direct, uint32_t slots, bool reuse,
                      Counters *c, bool wide) {
     if (wide)
-        launch_trace_di_w<T, true>(st, sc, fb, first, gi_on, add_direct, sample, spp, c);
+        launch_trace_di_w<T, true>(st, sc, fb, first, gi_on, add_direct, slots, reuse ? 1u : 0u, c);
     else
-        launch_trace_di_w<T, false>(st, sc, fb, first, gi_on, add_direct, sample, spp, c);
+        launch_trace_di_w<T, false>(st, sc, fb, first, gi_on, add_direct, slots, reuse ? 1u : 0u, c);
 }
-template <typename T> void launch_trace_gi(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, Counters *c) {
+template <typename T> void launch_trace_gi(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t slots, Counters *c) {
     if (c)
-        hipLaunchKernelGGL((k_trace_gi<T, true>), tile_grid(fb), dim3(256), 0, st, sc, fb, c);
+        hipLaunchKernelGGL((k_trace_gi<T, true>), tile_grid_z(fb, slots), dim3(256), 0, st, sc, fb, c);
     else
-        hipLaunchKernelGGL((k_trace_gi<T, false>), tile_grid(fb), dim3(256), 0, st, sc, fb, c);
+        hipLaunchKernelGGL((k_trace_gi<T, false>), tile_grid_z(fb, slots), dim3(256), 0, st, sc, fb, c);
+}
+template <typename T> void launch_spp_mean(hipStream_t st, const FrameDev<T> &fb, uint32_t first, uint32_t count, uint32_t spp) {
+    hipLaunchKernelGGL(k_spp_mean<T>, grid_for(fb.win.npix()), dim3(256), 0, st, fb, first, count, spp);
 }
 
-template <typename T, bool WIDE> static void launch_stream_gi_w(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t *counter, Counters *c) {
-    const uint32_t n_items = n_blocks8(fb) * 64u;
+template <typename T, bool WIDE>
+static void launch_stream_gi_w(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t slots, uint32_t *counter, Counters *c) {
+    const uint32_t per_slot = n_blocks8(fb) * 64u, n_items = per_slot * slots;
     if (c)
-        hipLaunchKernelGGL((k_stream_gi<T, true, WIDE>), stream_grid(k_stream_gi<T, true, WIDE>, n_items), dim3(256), 0, st, sc, fb, n_items, counter, c);
+        hipLaunchKernelGGL((k_stream_gi<T, true, WIDE>), stream_grid(k_stream_gi<T, true, WIDE>, n_items), dim3(256), 0, st, sc, fb, per_slot, n_items, counter, c);
     else
-        hipLaunchKernelGGL((k_stream_gi<T, false, WIDE>), stream_grid(k_stream_gi<T, false, WIDE>, n_items), dim3(256), 0, st, sc, fb, n_items, counter, c);
+        hipLaunchKernelGGL((k_stream_gi<T, false, WIDE>), stream_grid(k_stream_gi<T, false, WIDE>, n_items), dim3(256), 0, st, sc, fb, per_slot, n_items, counter, c);
 }
-template <typename T> void launch_shade2(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb) {
-    hipLaunchKernelGGL(k_shade2<T>, tile_grid(fb), dim3(256), 0, st, sc, fb);
+template <typename T> void launch_shade2(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t slots) {
+    hipLaunchKernelGGL(k_shade2<T>, tile_grid_z(fb, slots), dim3(256), 0, st, sc, fb);
 }
-template <typename T> void launch_stream_gi(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t *counter, Counters *c, bool wide) {
+template <typename T>
+void launch_stream_gi(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t slots, uint32_t *counter, Counters *c, bool wide) {
     if (wide)
-        launch_stream_gi_w<T, true>(st, sc, fb, counter, c);
+        launch_stream_gi_w<T, true>(st, sc, fb, slots, counter, c);
     else
-        launch_stream_gi_w<T, false>(st, sc, fb, counter, c);
+        launch_stream_gi_w<T, false>(st, sc, fb, slots, counter, c);
 }
 template <typename T, bool FIRST, bool WIDE>
-static void launch_stream_di_w(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t *counter, Counters *c) {
+static void launch_stream_di_w(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t slots, uint32_t *counter, Counters *c) {
     const uint32_t n_slots = std::min<uint32_t>(sc.n_lights, LPRT_MAX_DIRECT_LIGHT);
-    const uint32_t n_items = n_blocks8(fb) * 64u * n_slots;
+    const uint32_t per_slot = n_blocks8(fb) * 64u * n_slots, n_items = per_slot * slots;
     if (!n_items)
         return;
     if (c)
         hipLaunchKernelGGL((k_stream_di<T, FIRST, true, WIDE>), stream_grid(k_stream_di<T, FIRST, true, WIDE>, n_items), dim3(256), 0, st, sc, fb, n_slots,
-                           n_items, counter, c);
+                           per_slot, n_items, counter, c);
     else
         hipLaunchKernelGGL((k_stream_di<T, FIRST, false, WIDE>), stream_grid(k_stream_di<T, FIRST, false, WIDE>, n_items), dim3(256), 0, st, sc, fb, n_slots,
-                           n_items, counter, c);
+                           per_slot, n_items, counter, c);
 }
 template <typename T>
-void launch_stream_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, uint32_t *counter, Counters *c, bool wide) {
+void launch_stream_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, uint32_t slots, uint32_t *counter, Counters *c, bool wide) {
     if (first) {
         if (wide)
-            launch_stream_di_w<T, true, true>(st, sc, fb, counter, c);
+            launch_stream_di_w<T, true, true>(st, sc, fb, slots, counter, c);
         else
-            launch_stream_di_w<T, true, false>(st, sc, fb, counter, c);
+            launch_stream_di_w<T, true, false>(st, sc, fb, slots, counter, c);
     } else {
         if (wide)
-            launch_stream_di_w<T, false, true>(st, sc, fb, counter, c);
+            launch_stream_di_w<T, false, true>(st, sc, fb, slots, counter, c);
         else
-            launch_stream_di_w<T, false, false>(st, sc, fb, counter, c);
+            launch_stream_di_w<T, false, false>(st, sc, fb, slots, counter, c);
     }
 }
-template <typename T> void launch_accum_di(hipStream_t st, const FrameDev<T> &fb, bool first, bool gi_on, bool add_direct, uint32_t sample, uint32_t spp) {
-    const dim3 g = tile_grid(fb), b(256);
-    const ComposeArgs ca{gi_on ? 1 : 0, add_direct ? 1 : 0, sample, spp};
+template <typename T>
+void launch_accum_di(hipStream_t st, const FrameDev<T> &fb, bool first, bool gi_on, bool add_direct, uint32_t slots, bool reuse) {
+    const dim3 g = tile_grid_z(fb, slots), b(256);
+    const ComposeArgs ca{gi_on ? 1 : 0, add_direct ? 1 : 0, reuse ? 1u : 0u};
     if (first && gi_on)
         hipLaunchKernelGGL((k_accum_di<T, true, false>), g, b, 0, st, fb, ca);
     else if (first)
@@ -944,16 +991,17 @@ void launch_stream_rays(hipStream_t st, const SceneDev<T> &sc, const lprt_ray *r
 }
 
 #define INST(T)                                                                                                        \
-    template void launch_stream_gi<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, uint32_t *, Counters *, bool); \
-    template void launch_shade2<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &);                             \
-    template void launch_stream_di<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, uint32_t *, Counters *, bool); \
-    template void launch_accum_di<T>(hipStream_t, const FrameDev<T> &, bool, bool, bool, uint32_t, uint32_t);          \
+    template void launch_stream_gi<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, uint32_t, uint32_t *, Counters *, bool); \
+    template void launch_shade2<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, uint32_t);                   \
+    template void launch_stream_di<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, uint32_t, uint32_t *, Counters *, bool); \
+    template void launch_accum_di<T>(hipStream_t, const FrameDev<T> &, bool, bool, bool, uint32_t, bool);              \
+    template void launch_spp_mean<T>(hipStream_t, const FrameDev<T> &, uint32_t, uint32_t, uint32_t);                  \
     template void launch_stream_rays<T>(hipStream_t, const SceneDev<T> &, const lprt_ray *, uint32_t, bool, bool, lprt_hit *, uint32_t *, Counters *); \
     template void launch_fill_gbuffer<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, Counters *);          \
     template void launch_temporal_map<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, uint32_t);      \
-    template void launch_shade<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, uint32_t, uint32_t, bool); \
-    template void launch_trace_di<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, bool, bool, uint32_t, uint32_t, Counters *, bool); \
-    template void launch_trace_gi<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, Counters *);
+    template void launch_shade<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, const SampleBatch &);   \
+    template void launch_trace_di<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, bool, bool, uint32_t, bool, Counters *, bool); \
+    template void launch_trace_gi<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, uint32_t, Counters *);
 INST(float)
 INST(h16)
 #undef INST

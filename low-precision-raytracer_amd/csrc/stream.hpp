@@ -23,13 +23,6 @@
 namespace lprt {
 
 
-// what a finished closest-hit ray leaves for the per-pixel stage that follows (k_shade2): Intersection<DataT>, packed
-template <typename T> struct alignas(8) GiHit { // 24 B (f32) / 16 B (f16)
-    uint32_t objid_hit; // bit 31: hit; low bits: inscene_objid
-    uint32_t inobject_offset;
-    T bx, by, bz, t;
-};
-
 // box test of the walk: trace.hpp's slab test + culls, the stationary-axis rejection as a run-time (wave-skipped) branch
 template <typename T>
 LPRT_DEV bool stream_box(const T *lo, const T *hi, const RaySlab<T> &rs, float best_t, float min_d, float max_d, float &tnear) {

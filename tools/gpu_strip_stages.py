@@ -1,5 +1,5 @@
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import lprt_amd
 from lprt_amd import abi, scenes, dist as lp_dist
 sc = scenes.SCENES["cornell"]()

@@ -11,7 +11,7 @@ cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ff
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur, rows = None, {}
 for line in out.splitlines():
-    m = re.search(r"remark: (?:Function Name: (\S+)|\s+(\w[\w ]*): (\d+))", line)
+    m = re.search(r"remark: (?:Function Name: (\S+)|\s+([\w \[\]/]+?): (\d+))", line)
     if not m:
         continue
     if m.group(1):
@@ -22,4 +22,4 @@ for line in out.splitlines():
 for k, d in sorted(rows.items(), key=lambda kv: short(kv[0])):
     name = short(k) + (" " + "".join(re.findall(r"Lb([01])E", k.split("EEv")[0])) if "Lb" in k else "")
     if flt in name:
-        print(f"{name:44s} VGPR {d.get('VGPRs', 0):3d} AGPR {d.get('AGPRs', 0):3d} scratch {d.get('ScratchSize [bytes/lane]', 0):4d} B  waves/SIMD {d.get('Occupancy [waves/SIMD]', 0)}  LDS {d.get('LDS Size [bytes/block]', 0)}")
+        print(f"{name:44s} VGPR {d.get('VGPRs', 0):3d} AGPR {d.get('AGPRs', 0):3d} scratch {d.get('ScratchSize [bytes/lane]', 0):4d} B  spills v{d.get('VGPRs Spill', 0)} s{d.get('SGPRs Spill', 0)}  waves/SIMD {d.get('Occupancy [waves/SIMD]', 0)}  LDS {d.get('LDS Size [bytes/block]', 0)}")
