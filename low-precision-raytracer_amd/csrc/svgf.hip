@@ -554,12 +554,21 @@ __global__ void __launch_bounds__(256) k_finalize(SceneDev<T> sc, FrameDev<T> fb
     fb.prev_frame_count[p] = fb.valid_frame_count[p]; // snapshot for the next frame's temporal map
 }
 
-// copy_last_frame_transform (cuda.hpp:2253-2263)
+// copy_last_frame_transform (cuda.hpp:2253-2263).  The slot is indexed by objectid (the VAO), so instances that share a mesh
+// write the same slot: in the reference that is a race between threads (whichever instance's store lands last is the
+// "last frame transform" of all of them); the oracle's sequential loop makes the LAST instance in index order win, and so
+// does this kernel -- a thread stores only if no later instance names its VAO (n <= 1024 instances: the scan is nothing).
+// Found by tests/test_gpu_frame.py::test_launch_structure_never_changes_a_frame: the 150-instance field rendered its
+// second frame differently from run to run.
 template <typename T> __global__ void k_copy_last_transform(SceneDev<T> sc, M4<T> *last_L2W, uint32_t n) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
         return;
-    last_L2W[sc.objects[i].objectid] = sc.objects[i].L2W;
+    const uint32_t id = sc.objects[i].objectid;
+    for (uint32_t j = i + 1; j < n; j++)
+        if (sc.objects[j].objectid == id)
+            return;
+    last_L2W[id] = sc.objects[i].L2W;
 }
 
 // float32 read-back conversions

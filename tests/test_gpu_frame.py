@@ -151,6 +151,33 @@ def test_atrium_frames_with_per_frame_rebuild_match_oracle_ray_by_ray(sponza, pr
 
 
 @pytest.mark.parametrize("prec", [abi.F32, abi.F16])
+@pytest.mark.parametrize("scene_name,W,H", [("sponza_like", 256, 144), ("instanced_field", 160, 90), ("cornell", 160, 96)])
+def test_launch_structure_never_changes_a_frame(scene_name, W, H, prec):
+    """How the rays are launched is a matter of speed only.  Ray streams (csrc/stream.hpp: persistent waves that refill
+    finished lanes; flat instance scan on the atrium and Cornell, the TLAS tree walk on the 150-instance field) against one
+    ray per lane in the fused kernels, and 1 / 2 / 8 samples per launch (sample slots, k_spp_mean in sample order): three
+    frames at 3 spp come out bit-identical -- display image, the last sample's radiance of both rounds, the denoiser's
+    input -- for every combination, and so do the ray counts."""
+    sc = scenes.SCENES[scene_name]()
+    outs = {}
+    for stream, batch in ((0, 1), (0, 8), (1, 1), (1, 2), (1, 8), (-1, 8)):
+        with lprt_amd.Renderer(W, H, prec) as r:
+            r.set_option("ray_stream", stream)
+            r.set_option("sample_batch", batch)
+            r.load_scene(sc)
+            r.enable_counters(True)
+            for _ in range(3):
+                r.set_scene(sc)
+                r.render(abi.default_settings(spp=3))
+            outs[(stream, batch)] = [r.read(n) for n in ("OUTPUT", "INTENSITY0", "INTENSITY1", "RAW_GI_COLORED", "RAW_COLOR", "GI_DIRECTION")] + \
+                                    [np.array([r.stage_counters(st)["rays"] for st in ("primary", "trace_di1", "trace_gi", "trace_di2")])]
+    first = outs[(0, 1)]
+    for key, got in outs.items():
+        for a, b in zip(first, got):
+            assert np.array_equal(a, b, equal_nan=True), key
+
+
+@pytest.mark.parametrize("prec", [abi.F32, abi.F16])
 def test_rebuilding_every_blas_inside_the_frame_changes_nothing(sponza, prec):
     """lprt_frame_settings.rebuild_blas (config C4): three frames with the BLAS set rebuilt on the GPU before each one are
     bit-identical to three frames over the BLAS built once -- the build is deterministic and nothing of the old hierarchy
@@ -658,6 +685,23 @@ def test_moving_objects_and_camera_reproject_like_the_oracle(cornell, prec):
         still.set_scene(cornell)
         still.render(abi.default_settings(spp=1))
     assert rel_l2(still.read("OUTPUT"), r.read("OUTPUT")) > 1e-2
+
+
+def test_instances_sharing_a_mesh_reproject_like_the_oracle():
+    """copy_last_frame_transform (cuda.hpp:2253-2263) keeps ONE last-frame transform per VAO: instances that share a mesh
+    write the same slot (a race in the reference; the last instance in index order in the oracle's loop and in
+    k_copy_last_transform), so the temporal maps of all but one instance of a mesh reproject through another instance's
+    transform.  Three frames of the 150-instance field: every radiance plane within tolerance of the oracle on frames that
+    use history, and the same frames from two runs (the race made frame 1 differ from run to run)."""
+    sc = scenes.instanced_field(150)
+    W, H = 160, 90
+    runs = []
+    for _ in range(2):
+        r, o = render_pair(sc, W, H, abi.F32, frames=3, spp=1)
+        for name in RADIANCE:
+            assert rel_l2(r.read(name), o.read(name)) < TOL[abi.F32], name
+        runs.append(r.read("OUTPUT"))
+    assert np.array_equal(runs[0], runs[1], equal_nan=True)
 
 
 @pytest.mark.parametrize("prec,name", [(abi.F32, "f32"), (abi.F16, "f16")])

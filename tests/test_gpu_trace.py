@@ -280,6 +280,31 @@ def test_tlas_tree_walk_with_many_instances():
     assert o.trace(rays, False)["hit"].mean() > 0.2
 
 
+@pytest.mark.parametrize("scene_name,n", [("instanced_field", 50000), ("sponza_like", 40000), ("small_test", 30000)])
+def test_ray_stream_hit_records_equal_the_per_pixel_walk_and_the_oracle(scene_name, n):
+    """lprt_trace_rays through the persistent stream kernel (LPRT_OPT_RAY_STREAM = 1: TLAS tree walk on the 150-instance
+    field, flat scan elsewhere, one- and two-level BLAS steps) against the one-ray-per-lane kernel: identical hit records,
+    closest and any, both precisions; and against the oracle in single precision."""
+    sc = scenes.SCENES[scene_name]() if scene_name != "instanced_field" else scenes.instanced_field(150)
+    for prec, tmin in ((abi.F32, 1e-4), (abi.F16, 0.1)):
+        rays = random_rays(sc, n, 31, tmin)
+        hits = {}
+        for stream in (0, 1):
+            with lprt_amd.Renderer(16, 16, prec) as r:
+                r.set_option("ray_stream", stream)
+                r.load_scene(sc)
+                hits[stream] = (r.trace(rays, False), r.trace(rays, True))
+        for any_hit in (0, 1):
+            a, b = hits[0][any_hit], hits[1][any_hit]
+            for f in ("hit", "inscene_objid", "inobject_offset", "t", "barycentric"):
+                assert np.array_equal(a[f], b[f]), (prec, any_hit, f)
+        if prec == abi.F32:
+            with Oracle(16, 16, prec) as o:
+                o.load_scene(sc)
+                for any_hit in (False, True):
+                    compare_hits(o.trace(rays, any_hit), hits[1][int(any_hit)], any_hit, 0.01)
+
+
 def test_local_subtree_ordering_equals_the_all_global_build(sponza, small_scene):
     """build.hip: below 1024 triangles per node one workgroup finishes the subtree's median ordering in LDS (bitonic sort
     of sub-node | key | position); the permutation must be the one the level-by-level global radix sorts produce."""
