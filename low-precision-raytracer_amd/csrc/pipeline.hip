@@ -673,11 +673,12 @@ template <typename T> static inline uint32_t n_blocks8(const FrameDev<T> &fb) { 
 
 template <typename T> struct GiSource { // trace_gi's rays (cuda.hpp:2083-2105): one item per pixel and sample slot
     FrameDev<T> fb0;
-    uint32_t per_slot; // items of one sample slot
+    uint32_t slots; // sample slots of the batch: the runs of 64 items of one 8x8 block are adjacent, one per slot (the
+                    // samples of a pixel start at the same point: consecutive batches of a wave walk the same part of the scene)
     LPRT_DEV bool load(uint32_t item, RayT<T> &ray, T &tmin, T &tmax, uint32_t &skip_vao, uint32_t &skip_off) const {
-        const uint32_t z = item / per_slot, it = item - z * per_slot;
+        const uint32_t run = item >> 6, z = run % slots;
         const FrameDev<T> fb = at_sample(fb0, z);
-        const uint32_t p = block_pixel(fb, it >> 6, it & 63u);
+        const uint32_t p = block_pixel(fb, run / slots, item & 63u);
         if (p == 0xffffffffu || !fb.gi_valid[p])
             return false;
         const uint2 skip = fb.skips[p];
@@ -690,9 +691,9 @@ template <typename T> struct GiSource { // trace_gi's rays (cuda.hpp:2083-2105):
         return true;
     }
     LPRT_DEV void store(uint32_t item, const Isect<T> &is) const {
-        const uint32_t z = item / per_slot, it = item - z * per_slot;
+        const uint32_t run = item >> 6, z = run % slots;
         const FrameDev<T> fb = at_sample(fb0, z);
-        const uint32_t p = block_pixel(fb, it >> 6, it & 63u);
+        const uint32_t p = block_pixel(fb, run / slots, item & 63u);
         GiHit<T> h;
         h.objid_hit = (is.hit ? 0x80000000u : 0u) | is.inscene_objid;
         h.inobject_offset = is.inobject_offset;
@@ -705,14 +706,15 @@ template <typename T> struct GiSource { // trace_gi's rays (cuda.hpp:2083-2105):
 };
 template <typename T, bool FIRST> struct DiSource { // trace_di_light's rays (cuda.hpp:2058-2081): one item per pixel, light slot and sample slot
     FrameDev<T> fb0;
-    uint32_t n_slots;  // min(n_lights, 4): items of one 8x8 block = n_slots runs of 64, slot-major (a wave's rays aim at one light)
-    uint32_t per_slot; // items of one sample slot
+    uint32_t n_slots; // min(n_lights, 4)
+    uint32_t slots;   // sample slots of the batch.  Items of one 8x8 block: slots x n_slots runs of 64, sample slot outer, light
+                      // slot inner (a run's rays aim at one light)
     LPRT_DEV FrameDev<T> where(uint32_t item, uint32_t &p, uint32_t &slot) const {
-        const uint32_t z = item / per_slot, it = item - z * per_slot;
-        const FrameDev<T> fb = at_sample(fb0, z);
-        const uint32_t run = it >> 6;
+        const uint32_t run = item >> 6;
         slot = run % n_slots;
-        p = block_pixel(fb, run / n_slots, it & 63u);
+        const uint32_t r2 = run / n_slots, z = r2 % slots;
+        const FrameDev<T> fb = at_sample(fb0, z);
+        p = block_pixel(fb, r2 / slots, item & 63u);
         return fb;
     }
     LPRT_DEV bool load(uint32_t item, RayT<T> &ray, T &tmin, T &tmax, uint32_t &skip_vao, uint32_t &skip_off) const {
@@ -764,18 +766,18 @@ template <typename T> struct HostRaySource { // lprt_trace_rays
 };
 
 template <typename T, bool COUNT, bool WIDE>
-__global__ void __launch_bounds__(256, LPRT_STREAM_WAVES) k_stream_gi(SceneDev<T> sc, FrameDev<T> fb, uint32_t per_slot, uint32_t n_items, uint32_t *counter,
+__global__ void __launch_bounds__(256, LPRT_STREAM_WAVES) k_stream_gi(SceneDev<T> sc, FrameDev<T> fb, uint32_t slots, uint32_t n_items, uint32_t *counter,
                                                                        Counters *counters) {
     Cnt<COUNT> cnt;
-    GiSource<T> src{fb, per_slot};
+    GiSource<T> src{fb, slots};
     trace_stream<T, false, COUNT, WIDE>(sc, src, n_items, counter, cnt);
     flush_counters<COUNT>(cnt, counters);
 }
 template <typename T, bool FIRST, bool COUNT, bool WIDE>
-__global__ void __launch_bounds__(256, LPRT_STREAM_WAVES) k_stream_di(SceneDev<T> sc, FrameDev<T> fb, uint32_t n_slots, uint32_t per_slot, uint32_t n_items,
+__global__ void __launch_bounds__(256, LPRT_STREAM_WAVES) k_stream_di(SceneDev<T> sc, FrameDev<T> fb, uint32_t n_slots, uint32_t slots, uint32_t n_items,
                                                                        uint32_t *counter, Counters *counters) {
     Cnt<COUNT> cnt;
-    DiSource<T, FIRST> src{fb, n_slots, per_slot};
+    DiSource<T, FIRST> src{fb, n_slots, slots};
     trace_stream<T, true, COUNT, WIDE>(sc, src, n_items, counter, cnt);
     flush_counters<COUNT>(cnt, counters);
 }
@@ -916,9 +918,9 @@ template <typename T, bool WIDE>
 static void launch_stream_gi_w(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t slots, uint32_t *counter, Counters *c) {
     const uint32_t per_slot = n_blocks8(fb) * 64u, n_items = per_slot * slots;
     if (c)
-        hipLaunchKernelGGL((k_stream_gi<T, true, WIDE>), stream_grid(k_stream_gi<T, true, WIDE>, n_items), dim3(256), 0, st, sc, fb, per_slot, n_items, counter, c);
+        hipLaunchKernelGGL((k_stream_gi<T, true, WIDE>), stream_grid(k_stream_gi<T, true, WIDE>, n_items), dim3(256), 0, st, sc, fb, slots, n_items, counter, c);
     else
-        hipLaunchKernelGGL((k_stream_gi<T, false, WIDE>), stream_grid(k_stream_gi<T, false, WIDE>, n_items), dim3(256), 0, st, sc, fb, per_slot, n_items, counter, c);
+        hipLaunchKernelGGL((k_stream_gi<T, false, WIDE>), stream_grid(k_stream_gi<T, false, WIDE>, n_items), dim3(256), 0, st, sc, fb, slots, n_items, counter, c);
 }
 template <typename T> void launch_shade2(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t slots) {
     hipLaunchKernelGGL(k_shade2<T>, tile_grid_z(fb, slots), dim3(256), 0, st, sc, fb);
@@ -938,10 +940,10 @@ static void launch_stream_di_w(hipStream_t st, const SceneDev<T> &sc, const Fram
         return;
     if (c)
         hipLaunchKernelGGL((k_stream_di<T, FIRST, true, WIDE>), stream_grid(k_stream_di<T, FIRST, true, WIDE>, n_items), dim3(256), 0, st, sc, fb, n_slots,
-                           per_slot, n_items, counter, c);
+                           slots, n_items, counter, c);
     else
         hipLaunchKernelGGL((k_stream_di<T, FIRST, false, WIDE>), stream_grid(k_stream_di<T, FIRST, false, WIDE>, n_items), dim3(256), 0, st, sc, fb, n_slots,
-                           per_slot, n_items, counter, c);
+                           slots, n_items, counter, c);
 }
 template <typename T>
 void launch_stream_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, uint32_t slots, uint32_t *counter, Counters *c, bool wide) {
