@@ -36,15 +36,20 @@ struct TopVectors {
 // The wave's current matrix (5 KB) is staged in LDS with vector loads and its columns are then read back as
 // wave-uniform broadcasts: scalar loads of the columns (the obvious form) are limited by scalar-cache fills.
 // acc ^= column & mask is ONE v_bitop3_b32 (truth table 0x78 = a ^ (b & c)).
+// Results leave through registers: a lane keeps the 4 consecutive destinations (its wave's 4 j) of each of its two
+// sources and stores them as one 16-byte vector per state word -- the four waves of a block complete the 64-byte line.
+// (Round 1 transposed them through a 43.5-KB LDS tile for 64-byte runs per source; with the 20 KB of staged matrices that
+// was 64 KB per workgroup = two workgroups per CU = TWO waves per SIMD for a kernel that does nothing but issue
+// v_bitop3: rocprofv3 showed SQ_ACTIVE_INST_VALU at 0.49 of the wave cycles, half the issue rate.  Without the tile the
+// limit is the registers: 4 waves per SIMD.)
 // blockIdx.z = seed of a batch: src / dst planes of seed z start at z * src_seed_stride / z * dst_seed_stride.
 constexpr int RNG_S = 128; // sources per block
 LPRT_DEV uint32_t xor_and(uint32_t acc, uint32_t col, uint32_t mask) { return __builtin_amdgcn_bitop3_b32(acc, col, mask, 0x78); }
 template <int TOP>
-__global__ void __launch_bounds__(256) k_rng_expand(const XorMat *__restrict__ P, const uint32_t *__restrict__ src, TopBatch topb, TopVectors top1,
-                                                    uint32_t n_src, uint32_t src_stride, uint32_t src_seed_stride, uint32_t *__restrict__ dst,
-                                                    uint32_t dst_first, uint32_t dst_count, uint32_t dst_stride, uint32_t dst_seed_stride) {
+__global__ void __launch_bounds__(256, 4) k_rng_expand(const XorMat *__restrict__ P, const uint32_t *__restrict__ src, TopBatch topb, TopVectors top1,
+                                                       uint32_t n_src, uint32_t src_stride, uint32_t src_seed_stride, uint32_t *__restrict__ dst,
+                                                       uint32_t dst_first, uint32_t dst_count, uint32_t dst_stride, uint32_t dst_seed_stride) {
     __shared__ uint4 mat[4][160 * 2]; // [wave][column][8 words]
-    __shared__ uint32_t tile[5][RNG_S][17];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t sA = blockIdx.x * RNG_S + lane, sB = sA + 64;
     const uint32_t jbase = blockIdx.y * 16;
@@ -58,6 +63,8 @@ __global__ void __launch_bounds__(256) k_rng_expand(const XorMat *__restrict__ P
         if (sB < n_src)
             vb[k] = TOP == 2 ? topb.v[z][k][sB & 15] : (TOP == 1 ? top1.v[k][sB & 63] : src[k * src_stride + sB]);
     }
+    uint32_t ra[5][4], rb[5][4]; // [state word][j of this wave]
+#pragma unroll
     for (uint32_t jj = 0; jj < 4; jj++) {
         const uint32_t jl = wave * 4 + jj; // 0..15 within the block
         const uint4 *m = reinterpret_cast<const uint4 *>(P + jbase + jl);
@@ -88,30 +95,37 @@ __global__ void __launch_bounds__(256) k_rng_expand(const XorMat *__restrict__ P
                 b4 = xor_and(b4, c4, mb);
             }
         }
-        tile[0][lane][jl] = a0;
-        tile[1][lane][jl] = a1;
-        tile[2][lane][jl] = a2;
-        tile[3][lane][jl] = a3;
-        tile[4][lane][jl] = a4;
-        tile[0][lane + 64][jl] = b0;
-        tile[1][lane + 64][jl] = b1;
-        tile[2][lane + 64][jl] = b2;
-        tile[3][lane + 64][jl] = b3;
-        tile[4][lane + 64][jl] = b4;
+        ra[0][jj] = a0; ra[1][jj] = a1; ra[2][jj] = a2; ra[3][jj] = a3; ra[4][jj] = a4;
+        rb[0][jj] = b0; rb[1][jj] = b1; rb[2][jj] = b2; rb[3][jj] = b3; rb[4][jj] = b4;
         __builtin_amdgcn_wave_barrier(); // the next staging overwrites mat[wave]: all lanes must be done reading
     }
-    __syncthreads();
-    // coalesced write-out: for each of the 128 sources, 16 consecutive destinations
-    for (uint32_t e = threadIdx.x; e < RNG_S * 16; e += 256) {
-        const uint32_t sl = e >> 4, jl = e & 15;
-        const uint32_t ss = blockIdx.x * RNG_S + sl;
+    // write-out: destinations n0 .. n0+3 of a source are consecutive; one 16-byte store per state word when the run lies
+    // inside [dst_first, dst_first + dst_count) and starts on a 16-byte boundary of its plane, single words otherwise
+    const bool planes_aligned = ((reinterpret_cast<uintptr_t>(dst) | ((size_t)dst_stride * 4u)) & 15u) == 0u;
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const uint32_t ss = half == 0 ? sA : sB;
         if (ss >= n_src)
             continue;
-        const uint32_t n = ss * 64 + jbase + jl;
-        if (n < dst_first || n - dst_first >= dst_count)
-            continue;
-        for (int k = 0; k < 5; k++)
-            dst[k * dst_stride + (n - dst_first)] = tile[k][sl][jl];
+        const uint32_t n0 = ss * 64 + jbase + wave * 4;
+        const bool inside = n0 >= dst_first && n0 - dst_first + 4u <= dst_count;
+        if (inside && planes_aligned && ((n0 - dst_first) & 3u) == 0u) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const uint32_t *r = half == 0 ? ra[k] : rb[k];
+                *reinterpret_cast<uint4 *>(dst + (size_t)k * dst_stride + (n0 - dst_first)) = make_uint4(r[0], r[1], r[2], r[3]);
+            }
+        } else {
+#pragma unroll
+            for (uint32_t jj = 0; jj < 4; jj++) {
+                const uint32_t n = n0 + jj;
+                if (n < dst_first || n - dst_first >= dst_count)
+                    continue;
+#pragma unroll
+                for (int k = 0; k < 5; k++)
+                    dst[(size_t)k * dst_stride + (n - dst_first)] = half == 0 ? ra[k][jj] : rb[k][jj];
+            }
+        }
     }
 }
 
