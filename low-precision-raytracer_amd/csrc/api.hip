@@ -536,7 +536,7 @@ template <typename T> struct Impl : CtxBase {
             // svgf_denoise (cuda.hpp:1636-1711), both lobes per launch
             stage(LPRT_STAGE_SVGF_GRADIENT, [&] { launch_depth_gradient<T>(stream, fb); });
             const bool always_test = opts[LPRT_OPT_SVGF_ALWAYS_TEST] != 0;
-            stage(LPRT_STAGE_SVGF_TEMPORAL, [&] { launch_temporal_color<T>(stream, fb, fs.svgf_color_mix_weight, always_test); });
+            stage(LPRT_STAGE_SVGF_TEMPORAL, [&] { launch_temporal_color<T>(stream, fb, fs.svgf_color_mix_weight, fs.svgf_moments_mix_weight, always_test); });
             stage(LPRT_STAGE_SVGF_MOMENTS, [&] { launch_moments<T>(stream, fb, fs.svgf_moments_mix_weight); });
             for (int level = 0; level < 5; level++)
                 stage(LPRT_STAGE_SVGF_WAVELET, [&] { launch_wavelet<T>(stream, fb, level, always_test); });

@@ -56,7 +56,7 @@ void launch_stream_rays(hipStream_t st, const SceneDev<T> &sc, const lprt_ray *r
 
 // svgf.hip
 template <typename T> void launch_depth_gradient(hipStream_t st, const FrameDev<T> &fb);
-template <typename T> void launch_temporal_color(hipStream_t st, const FrameDev<T> &fb, float color_w, bool always_test);
+template <typename T> void launch_temporal_color(hipStream_t st, const FrameDev<T> &fb, float color_w, float moments_w, bool always_test); // + the moments of pixels with >= 4 frames of history
 template <typename T> void launch_moments(hipStream_t st, const FrameDev<T> &fb, float moments_w);
 template <typename T> void launch_wavelet(hipStream_t st, const FrameDev<T> &fb, int level, bool always_test);
 template <typename T>

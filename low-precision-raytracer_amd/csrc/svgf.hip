@@ -100,7 +100,7 @@ template <typename T> struct PackedV4 { // a V4<T> as two pairs for packed arith
     v2 xy, zw;
 };
 template <typename T>
-__global__ void __launch_bounds__(256) k_temporal_color(FrameDev<T> fb, T color_w, int always_test) {
+__global__ void __launch_bounds__(256) k_temporal_color(FrameDev<T> fb, T color_w, T moments_w, int always_test) {
     __shared__ V4<T> tile[2][TC_TH][TC_TW];
     __shared__ uint32_t s_nonfinite; // some staged colour component is inf / NaN: the window sums must test every sample
     const int W = (int)fb.win.W, R = (int)fb.win.rows();
@@ -193,8 +193,25 @@ __global__ void __launch_bounds__(256) k_temporal_color(FrameDev<T> fb, T color_
         value_or(hist, pc);
         V3<T> out = color_w * pc + (one - color_w) * hist;
         T illum = cvt<T>(0.2126f) * out.x + cvt<T>(0.7152f) * out.y + cvt<T>(0.0722f) * out.z;
-        fb.lobe[l].cv_c[p] = mk4(out.x, out.y, out.z, zero);
         fb.lobe[l].illum[p] = illum;
+        // temporal_accumulation_moments for a pixel with >= 4 frames of history needs nothing but this pixel's luminance and
+        // its history taps (cuda.hpp:1307-1330): done here, in the thread that has both -- k_moments keeps the pixels whose
+        // moments come from the 5x5 neighbourhood of THIS pass's output (frame_count < 4).
+        T lvar = zero; // variance of the luminance (cv_c.w)
+        if (ti.frame_count >= 4u) {
+            const T i2 = illum * illum;
+            T miu1 = (one - moments_w) * sample_linear1(ti, fb.lobe[l].miu1_hist, fb.win.W, zero) + illum * moments_w;
+            T miu2 = (one - moments_w) * sample_linear1(ti, fb.lobe[l].miu2_hist, fb.win.W, zero) + i2 * moments_w;
+            if (!tfinite(miu1))
+                miu1 = illum;
+            if (!tfinite(miu2))
+                miu2 = i2;
+            fb.lobe[l].miu1_cur[p] = miu1;
+            fb.lobe[l].miu2_cur[p] = miu2;
+            lvar = miu2 - miu1 * miu1; // variance, not clamped at 0
+            fb.lobe[l].var_c[p] = lvar;
+        }
+        fb.lobe[l].cv_c[p] = mk4(out.x, out.y, out.z, lvar);
     }
 }
 
@@ -225,18 +242,18 @@ LPRT_DEV void geo_weights(T depth_p, T depth_q, V2<T> grad, T dx, T dy, V3<T> n_
 
 // ---- temporal_accumulation_moments (cuda.hpp:1245-1337), both lobes ---------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(256) k_moments(FrameDev<T> fb, T moments_w) {
+__global__ void __launch_bounds__(256) k_moments(FrameDev<T> fb) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= fb.win.npix())
         return;
+    if (fb.valid_frame_count[p] >= 4u) // (= svgf_map[p].frame_count) done by k_temporal_color
+        return;
     const int W = (int)fb.win.W, R = (int)fb.win.rows();
     const int px = (int)(p % fb.win.W), py = (int)(p / fb.win.W);
-    const TemporalMapT<T> ti = fb.svgf_map[p];
-    const T zero = (T)0, one = (T)1;
+    const T zero = (T)0;
     const T hk[3] = {cvt<T>(0.375f), cvt<T>(0.25f), cvt<T>(0.0625f)};
-    T illum[2] = {fb.lobe[0].illum[p], fb.lobe[1].illum[p]};
     T miu1[2] = {zero, zero}, miu2[2] = {zero, zero};
-    if (ti.frame_count < 4) {
+    { // frame_count < 4: spatial estimate over the 5x5 neighbourhood (cuda.hpp:1262-1305)
         const V4<T> nd_p = fb.g_normal_depth[p];
         const V2<T> grad = fb.depth_gradient[p];
         T weight[2] = {zero, zero};
@@ -271,17 +288,6 @@ __global__ void __launch_bounds__(256) k_moments(FrameDev<T> fb, T moments_w) {
         for (int l = 0; l < 2; l++) {
             miu1[l] = tdiv(miu1[l], weight[l]);
             miu2[l] = tdiv(miu2[l], weight[l]);
-        }
-    } else {
-#pragma unroll
-        for (int l = 0; l < 2; l++) {
-            T i2 = illum[l] * illum[l];
-            miu1[l] = (one - moments_w) * sample_linear1(ti, fb.lobe[l].miu1_hist, fb.win.W, miu1[l]) + illum[l] * moments_w;
-            miu2[l] = (one - moments_w) * sample_linear1(ti, fb.lobe[l].miu2_hist, fb.win.W, miu2[l]) + i2 * moments_w;
-            if (!tfinite(miu1[l]))
-                miu1[l] = illum[l];
-            if (!tfinite(miu2[l]))
-                miu2[l] = i2;
         }
     }
 #pragma unroll
@@ -606,12 +612,13 @@ static inline dim3 grid_for(uint32_t n) { return dim3((n + 255) / 256); }
 template <typename T> void launch_depth_gradient(hipStream_t st, const FrameDev<T> &fb) {
     hipLaunchKernelGGL(k_depth_gradient<T>, grid_for(fb.win.npix()), dim3(256), 0, st, fb);
 }
-template <typename T> void launch_temporal_color(hipStream_t st, const FrameDev<T> &fb, float color_w, bool always_test) {
+template <typename T> void launch_temporal_color(hipStream_t st, const FrameDev<T> &fb, float color_w, float moments_w, bool always_test) {
     dim3 grid((fb.win.W + TC_BX - 1) / TC_BX, (fb.win.rows() + TC_BY - 1) / TC_BY);
-    hipLaunchKernelGGL(k_temporal_color<T>, grid, dim3(256), 0, st, fb, (T)color_w, always_test ? 1 : 0);
+    hipLaunchKernelGGL(k_temporal_color<T>, grid, dim3(256), 0, st, fb, (T)color_w, (T)moments_w, always_test ? 1 : 0);
 }
 template <typename T> void launch_moments(hipStream_t st, const FrameDev<T> &fb, float moments_w) {
-    hipLaunchKernelGGL(k_moments<T>, grid_for(fb.win.npix()), dim3(256), 0, st, fb, (T)moments_w);
+    (void)moments_w; // the weight is only used by the history branch, which runs in k_temporal_color
+    hipLaunchKernelGGL(k_moments<T>, grid_for(fb.win.npix()), dim3(256), 0, st, fb);
 }
 // level = 0..4 -> stride 1,2,4,8,16.  Buffer rotation (cuda.hpp:1678-1710 with cv_c in the role of color_inout, which
 // holds the integrated colour): L1 c->b (b = next frame's history), L2 b->a, L3 a->c, L4 c->a, L5 a->c; result in cv_c.
@@ -653,7 +660,7 @@ void launch_read_u8(hipStream_t st, const uint8_t *src, float *dst, uint32_t n) 
 
 #define INST(T)                                                                                                        \
     template void launch_depth_gradient<T>(hipStream_t, const FrameDev<T> &);                                          \
-    template void launch_temporal_color<T>(hipStream_t, const FrameDev<T> &, float, bool);                             \
+    template void launch_temporal_color<T>(hipStream_t, const FrameDev<T> &, float, float, bool);                      \
     template void launch_moments<T>(hipStream_t, const FrameDev<T> &, float);                                          \
     template void launch_wavelet<T>(hipStream_t, const FrameDev<T> &, int, bool);                                      \
     template void launch_finalize<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, const V4<T> *,             \
