@@ -61,8 +61,21 @@ template <typename T> LPRT_DEV bool stationary_reject(const T *lo, const T *hi, 
            ((rs.par & 2u) && stationary_axis_outside((float)rs.o.y, lo[1], hi[1])) ||
            ((rs.par & 4u) && stationary_axis_outside((float)rs.o.z, lo[2], hi[2]));
 }
-// (bound - origin) / d: the difference in DataT, the quotient as a product with the f32 reciprocal
-template <typename T> LPRT_DEV float slab_t(T bound, T origin, float inv) { return (float)(T)(bound - origin) * inv; }
+// (bound - origin) / d: the difference in DataT, the quotient as a product with the f32 reciprocal.  Half: the product is
+// written as fma(diff, inv, +0) so that the conversion folds into one v_fma_mix_f32 (same value; a -0 product becomes +0,
+// which no comparison of the test can tell apart).
+template <typename T> LPRT_DEV float slab_t(T bound, T origin, float inv);
+template <> LPRT_DEV float slab_t<float>(float bound, float origin, float inv) { return (bound - origin) * inv; }
+template <> LPRT_DEV float slab_t<h16>(h16 bound, h16 origin, float inv) { return __builtin_fmaf((float)(h16)(bound - origin), inv, 0.0f); }
+
+// a0*b0 + a1*b1 + a2*b2 in f32 from DataT operands, summed left to right (row 2 of the triangle test, cuda.hpp:234-240).
+// Half: a product of two halves is exact in f32, so fma(a, b, s) rounds once exactly like the separate add -- and is one
+// v_fma_mix_f32 reading the halves directly instead of two conversions, a multiply and an add.
+template <typename T> LPRT_DEV float dot3_f32(T a0, T a1, T a2, T b0, T b1, T b2);
+template <> LPRT_DEV float dot3_f32<float>(float a0, float a1, float a2, float b0, float b1, float b2) { return a0 * b0 + a1 * b1 + a2 * b2; }
+template <> LPRT_DEV float dot3_f32<h16>(h16 a0, h16 a1, h16 a2, h16 b0, h16 b1, h16 b2) {
+    return __builtin_fmaf((float)a2, (float)b2, __builtin_fmaf((float)a1, (float)b1, (float)a0 * (float)b0));
+}
 
 // All six parameters finite (every ray that moves along all three axes: a product with a finite reciprocal can overflow to
 // +-inf, consistently signed, but never to NaN): entry = max3(min, min, min), exit = min3(max, max, max).
@@ -164,8 +177,8 @@ LPRT_DEV bool tri_test(const SceneDev<T> &sc, uint32_t rec, const RayT<T> &ray, 
     T Oy = Oy_0 + Oy_1 + Oy_2;
     T Dy = Dy_0 + Dy_1 + Dy_2;
     // row 2 and t always in fp32, from the DataT-rounded operands (cuda.hpp:234-240)
-    float Oz = (float)O0 * (float)r.m2[0] + (float)O1 * (float)r.m2[1] + (float)O2 * (float)r.m2[2];
-    float Dz = (float)D0 * (float)r.m2[0] + (float)D1 * (float)r.m2[1] + (float)D2 * (float)r.m2[2];
+    float Oz = dot3_f32<T>(O0, O1, O2, r.m2[0], r.m2[1], r.m2[2]);
+    float Dz = dot3_f32<T>(D0, D1, D2, r.m2[0], r.m2[1], r.m2[2]);
     float invDz = 1.0f / Dz;
     float t = -Oz * invDz;
     T t_Dx = cvt<T>(t * (float)Dx);
