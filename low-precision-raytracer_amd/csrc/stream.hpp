@@ -279,9 +279,7 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items, ui
                         if (D <= 1u) { // 1-3 triangles: no boxes worth testing (trace.hpp)
                             for (uint32_t q = 0; q < n_tris; q++) {
                                 const uint32_t rec = tri_base + q;
-                                if (skip_here && sc.tris[rec].inobject_offset == skip_off)
-                                    continue;
-                                tri_test<T, COUNT>(sc, rec, lray, obj_id, is, tmin, tmax, cnt);
+                                tri_test<T, COUNT>(sc, rec, lray, obj_id, is, tmin, tmax, cnt, skip_here, skip_off);
                                 if (ANY && is.hit)
                                     break;
                             }
@@ -382,9 +380,7 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items, ui
             leaf_range_dev(i - (1u << D), D, n_tris, l, r);
             for (uint32_t q = l; q < r; q++) {
                 const uint32_t rec = tri_base + q;
-                if (skip_here && sc.tris[rec].inobject_offset == skip_off) // cuda.hpp:446
-                    continue;
-                tri_test<T, COUNT>(sc, rec, lray, obj_id, is, tmin, tmax, cnt);
+                tri_test<T, COUNT>(sc, rec, lray, obj_id, is, tmin, tmax, cnt, skip_here, skip_off);
                 if (ANY && is.hit)
                     break;
             }
