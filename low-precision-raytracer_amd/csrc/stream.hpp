@@ -251,27 +251,27 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items, ui
                 src.store(item, is); // the ray is done
                 has_ray = false;
             } else {
-                const ObjRec<T> *ob = sc.objrecs + k; // fields are fetched as they are needed: the matrix only when it is one
+                const ObjHead<T> ob = load_obj_head(sc.objrecs + k); // one round trip; the matrix only when it is one
                 if (COUNT)
                     cnt.objects++;
-                if (ob->n_tris != 0u) {
-                    if (ob->pad[0] & 1u) { // identity W2L (make_objrec): the instance's ray is the world ray
+                if (ob.n_tris != 0u) {
+                    if (ob.pad[0] & 1u) { // identity W2L (make_objrec): the instance's ray is the world ray
                         lray = wray;
                         lrs = wrs;
                     } else {
-                        lray = transform_ray(wray, ob->W2L);
+                        lray = transform_ray(wray, sc.objrecs[k].W2L);
                         lrs = make_slab(lray, sc.axis_reject);
                     }
                     float tn;
                     if (COUNT)
                         cnt.blas_nodes++;
-                    if (stream_box(ob->root_lo, ob->root_hi, lrs, (float)is.t, (float)tmin, (float)tmax, tn)) {
-                        inner = sc.blas_inner + ob->inner_base;
-                        D = ob->depth;
-                        n_tris = ob->n_tris;
-                        tri_base = ob->tri_base;
-                        obj_id = ob->inscene_objid;
-                        skip_here = ob->vao_index == skip_vao;
+                    if (stream_box(ob.root_lo, ob.root_hi, lrs, (float)is.t, (float)tmin, (float)tmax, tn)) {
+                        inner = sc.blas_inner + ob.inner_base;
+                        D = ob.depth;
+                        n_tris = ob.n_tris;
+                        tri_base = ob.tri_base;
+                        obj_id = ob.inscene_objid;
+                        skip_here = ob.vao_index == skip_vao;
                         i = 1;
                         c = 0;
                         pend = 0;

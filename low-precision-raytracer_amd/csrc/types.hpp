@@ -52,13 +52,19 @@ template <typename T> struct alignas(16) ObjSlot {
 // Everything a ray needs to enter one object instance, in TLAS (Morton) slot order: the world box (aabbs_W), the
 // world->local transform and the BLAS header + root box.  The reference reaches these through four dependent
 // fetches (aabbs_W[i], inscene_objid[i] -> objects_constant[id] -> objects_bvh[vao] -> nodes[0]; cuda.hpp:544-563, 421-437).
-template <typename T> struct alignas(16) ObjRec {
-    T lo[3], hi[3];           // world-space box
-    T root_lo[3], root_hi[3]; // BLAS root box (object space)
-    M4<T> W2L;
+// The head is what a ray needs to ENTER the instance (BLAS header, root box, flags): 64 / 48 bytes fetched in one round trip
+// (trace.hpp::load_obj_head); the world box is read by the instance scan, the matrix only when it is not the identity.
+template <typename T> struct alignas(16) ObjHead {
     uint32_t inscene_objid, vao_index, n_tris, depth, tri_base, inner_base;
-    uint32_t pad[2];
+    uint32_t pad[2];          // pad[0] bit 0: W2L is exactly the identity (make_objrec)
+    T root_lo[3], root_hi[3]; // BLAS root box (object space)
+    T hpad[2];
 };
+template <typename T> struct alignas(16) ObjRec : ObjHead<T> {
+    T lo[3], hi[3]; // world-space box
+    M4<T> W2L;
+};
+static_assert(sizeof(ObjHead<float>) == 64 && sizeof(ObjHead<h16>) == 48, "ObjHead is a whole number of 16-byte vectors");
 // CUDAObjectConstantData<DataT> (memory.hpp:279-301)
 template <typename T> struct alignas(16) ObjConst {
     M4<T> L2W, W2L;
