@@ -63,6 +63,12 @@ def trace_bytes(counters, stage, prec):
             c["rays"] * RAY_IO[stage][i])
 
 
+# DESIGN.md 4.4 "Negative radiance in long half-precision sequences": reference behaviour, reproduced by the oracle
+HALF_OUTPUT_NOTE = ("half precision, reference behaviour reproduced pixel for pixel by the oracle (DESIGN.md 4.4, tests/test_gpu_long_sequences.py): "
+                    "the reprojection truncates history positions toward zero, border pixels extrapolate their own history, after ~15 frames "
+                    "their filtered radiance is negative and pow(negative, 1/2.2) in the output pass is NaN; LPRT_OPT_FLOOR_REPROJECTION=1 removes it")
+
+
 def dist_info():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -169,10 +175,11 @@ def measure(prec, sc, W, H, spp, steps, warmup, rank, world, device, stage_timin
     if stage_timing:
         stage = {k: v for k, v in r.stage_times().items() if v[1]}   # the dominant stage only, over the timed region
         r.enable_stage_timing(False)
-    out_ok = bool(torch.isfinite(last["image"]).all().item()) and bool((last["image"][..., 3] == 1).all().item())
+    nonfinite_px = int((~torch.isfinite(last["image"]).all(dim=-1)).sum().item())
+    out_ok = nonfinite_px == 0 and bool((last["image"][..., 3] == 1).all().item())
     res = dict(dt=dt, ms_per_step=1e3 * dt / steps, frames_per_s=steps / dt, frame_rays=frame_rays,
                mrays_per_s=frame_rays * steps / dt / 1e6, stage=stage, calib=calib, stage_counters=stage_counters,
-               finite=out_ok, window_rows=[win_b, win_e], build_blas_ms=build_ms,
+               finite=out_ok, nonfinite_px=nonfinite_px, window_rows=[win_b, win_e], build_blas_ms=build_ms,
                sample_rows=(win_e - win_b) if frame.trace_halo else (frame.end - frame.begin))
     r.close()
     return res
@@ -371,7 +378,7 @@ def main():
             "mrays_per_s_trace_kernels_only": (res32["frame_rays"] / 1e3 / sum(res32["calib"][k][0] for k in ("primary", "trace_di1", "trace_gi", "trace_di2")
                                                                                   if k in res32["calib"])) if res32["calib"] else None,
             "build_blas_ms": res32["build_blas_ms"], "build_mtris_per_s": sc.n_tris / 1e3 / res32["build_blas_ms"],
-            "output_finite": res32["finite"],
+            "output_finite": res32["finite"], "output_nonfinite_px": res32["nonfinite_px"],
             "stage_ms_per_frame": {k: v[0] for k, v in res32["calib"].items()},
             "stage_ms_note": "3 untimed calibration frames with every stage bracketed by HIP events; the timed region "
                              "instruments the dominant stage only (roofline.avg_launch_us)",
@@ -387,6 +394,7 @@ def main():
                            "frames_per_s": res16["frames_per_s"], "rays_per_frame": res16["frame_rays"], "dtype": "f16",
                            "workload": workload_text(sc, W, H, spp, abi.F16, args.rebuild_blas, args.reuse_direct_light), "baseline_config": bc16,
                            "speedup_vs_f32": res16["mrays_per_s"] / res32["mrays_per_s"],
+                           "output_finite": res16["finite"], "output_nonfinite_px": res16["nonfinite_px"], "output_note": HALF_OUTPUT_NOTE,
                            "stage_ms_per_frame": {k: v[0] for k, v in res16["calib"].items()},
                            "roofline": roofline_of(res16, abi.F16, W, spp, world, wkey) if res16["stage"] else None}
         out["roofline"] = roofline_of(res32, abi.F32, W, spp, world, wkey) if res32["stage"] else None
@@ -400,7 +408,7 @@ def main():
                          "value": res_c4["mrays_per_s"], "unit": "Mray/s", "dtype": "f16", "ms_per_step": res_c4["ms_per_step"],
                          "frames_per_s": res_c4["frames_per_s"], "rays_per_frame": res_c4["frame_rays"], "triangles": sc_c4.n_tris,
                          "build_blas_ms": res_c4["build_blas_ms"], "build_mtris_per_s": sc_c4.n_tris / 1e3 / res_c4["build_blas_ms"],
-                         "output_finite": res_c4["finite"], "stage_ms_per_frame": {k: v[0] for k, v in res_c4["calib"].items()},
+                         "output_finite": res_c4["finite"], "output_nonfinite_px": res_c4["nonfinite_px"], "output_note": HALF_OUTPUT_NOTE, "stage_ms_per_frame": {k: v[0] for k, v in res_c4["calib"].items()},
                          "roofline": roofline_of(res_c4, abi.F16, 1920, 8, world, k4) if res_c4["stage"] else None,
                          "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(sc_c4, 8, abi.F16, 480, 270, budget_s=10.0)}
         print(json.dumps(out))

@@ -413,7 +413,16 @@ typedef enum {
     LPRT_OPT_SAMPLE_BATCH = 12,     /* 1..8 (default 8): samples of a frame that run through each per-sample stage in one launch
                                      * (the samples are independent up to the spp mean, which is summed in sample order either way);
                                      * 1 = one launch per sample and stage, the reference's loop order.  LPRT_SAMPLE_BATCH */
-    LPRT_OPT_COUNT = 13
+    LPRT_OPT_FLOOR_REPROJECTION = 13, /* 0 (default): the reference's reprojection taps -- the fractional history position is
+                                     * truncated TOWARD ZERO (cuda.hpp:2300-2306, 2347-2353), so a position a fraction of a pixel
+                                     * outside the left / top image border gets the tap weights (1 + e, -e): an extrapolation.  In
+                                     * half precision the position of a static pixel is off by up to W * 2^-11 pixels, the
+                                     * border pixels extrapolate their own history frame after frame, and after ~15 frames the
+                                     * filtered radiance there turns negative, grows by 1.3-1.5x per frame and the output pass
+                                     * writes NaN (the oracle reproduces it pixel for pixel).  1: floor() -- such a
+                                     * position keeps the one tap inside the image at weight 1.  Every pixel whose history
+                                     * position is not negative is unaffected.  LPRT_FLOOR_REPROJECTION */
+    LPRT_OPT_COUNT = 14
 } lprt_option;
 int lprt_set_option(lprt_ctx *ctx, lprt_option option, int value);
 int lprt_get_option(lprt_ctx *ctx, lprt_option option, int *value);

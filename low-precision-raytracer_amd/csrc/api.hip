@@ -80,7 +80,7 @@ struct CtxBase {
     uint32_t sample_first = 0, sample_rows = 0; // 0 rows: the whole window
     int next_phase = LPRT_PHASE_SAMPLE;
     // behaviour knobs (lprt_option): initialised from the environment once, in lprt_create; never read from it afterwards
-    int opts[LPRT_OPT_COUNT] = {-1, -1, 1, 0, 0, 1, 0, -1, 0, 12, 20, 0, (int)LPRT_MAX_SAMPLE_BATCH};
+    int opts[LPRT_OPT_COUNT] = {-1, -1, 1, 0, 0, 1, 0, -1, 0, 12, 20, 0, (int)LPRT_MAX_SAMPLE_BATCH, 0};
     void options_from_environment() {
         if (const char *w = std::getenv("LPRT_WIDE_WALK"))
             opts[LPRT_OPT_WIDE_WALK] = w[0] == '1' ? 1 : 0;
@@ -100,6 +100,8 @@ struct CtxBase {
             opts[LPRT_OPT_RAY_STREAM] = r[0] == '1' ? 1 : 0;
         if (const char *r = std::getenv("LPRT_SAMPLE_BATCH"))
             opts[LPRT_OPT_SAMPLE_BATCH] = std::max(1, std::min((int)LPRT_MAX_SAMPLE_BATCH, std::atoi(r)));
+        if (const char *r = std::getenv("LPRT_FLOOR_REPROJECTION"))
+            opts[LPRT_OPT_FLOOR_REPROJECTION] = r[0] == '1' ? 1 : 0;
         if (const char *r = std::getenv("LPRT_STREAM_SCHED"))
             opts[LPRT_OPT_STREAM_SCHED] = r[0] == '1' ? 1 : 0;
         if (const char *r = std::getenv("LPRT_STREAM_WIDE_CLOSEST"))
@@ -529,7 +531,7 @@ template <typename T> struct Impl : CtxBase {
         SceneDev<T> sc = frame_scene();
         const bool first = frame_index == 0;
         fb.rng_state = d_rng_planes.as<uint32_t>(); // seed A's planes (frames >= 1)
-        stage(LPRT_STAGE_TEMPORAL_MAP, [&] { launch_temporal_map<T>(stream, sc, fb, first, jitter_d); });
+        stage(LPRT_STAGE_TEMPORAL_MAP, [&] { launch_temporal_map<T>(stream, sc, fb, first, jitter_d, opts[LPRT_OPT_FLOOR_REPROJECTION] != 0); });
         const V4<T> *res0 = fb.lobe[0].cv_a, *res1 = fb.lobe[1].cv_a;
         svgf_ran = fs.svgf != 0;
         if (fs.svgf) {

@@ -32,7 +32,7 @@ struct SampleBatch {
     uint32_t reuse_direct;                    // lprt_frame_settings.reuse_direct_light: round 0 runs for sample 0 only
 };
 template <typename T> void launch_fill_gbuffer(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, Counters *c);
-template <typename T> void launch_temporal_map(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, uint32_t rng_d);
+template <typename T> void launch_temporal_map(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, uint32_t rng_d, bool floor_taps);
 template <typename T> void launch_shade(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool no_gi, const SampleBatch &sb); // round 0; round 1 runs inside k_trace_gi / as k_shade2
 template <typename T>
 void launch_trace_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, bool gi_on, bool add_direct, uint32_t slots, bool reuse,

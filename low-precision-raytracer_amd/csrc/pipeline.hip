@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(256, LPRT_CLOSEST_WAVES) k_fill_gbuffer(SceneD
 // `first` = no history yet (DEVIATION Q7: frame_count = 0 everywhere).  The neighbours' previous frame counts
 // come from a snapshot plane (prev_frame_count), which replaces the reference's racy two-step scheme.
 template <typename T>
-__global__ void __launch_bounds__(256) k_temporal_map(SceneDev<T> sc, FrameDev<T> fb, int first, uint32_t rng_d) {
+__global__ void __launch_bounds__(256) k_temporal_map(SceneDev<T> sc, FrameDev<T> fb, int first, uint32_t rng_d, int floor_taps) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t npix = fb.win.npix();
     if (p >= npix)
@@ -188,7 +188,10 @@ __global__ void __launch_bounds__(256) k_temporal_map(SceneDev<T> sc, FrameDev<T
         // rows outside this GPU's window count as outside the image (sharded frames)
         { // svgf 2x2, pixel centre
             T fx = g_fx - cvt<T>(0.5f), fy = g_fy - cvt<T>(0.5f);
-            int lx = f2i((float)fx), ly = f2i((float)fy), ux = lx + 1, uy = ly + 1;
+            // f2i truncates toward zero as the reference's int() does: a position in (-1, 0) keeps lx = 0 and extrapolates
+            // (LPRT_OPT_FLOOR_REPROJECTION = 1: floor)
+            int lx = floor_taps ? (int)__builtin_floorf((float)fx) : f2i((float)fx), ly = floor_taps ? (int)__builtin_floorf((float)fy) : f2i((float)fy);
+            int ux = lx + 1, uy = ly + 1;
             int nx[4] = {lx, lx, ux, ux}, ny[4] = {ly, uy, ly, uy};
             T tux = cvt<T>((float)ux), tuy = cvt<T>((float)uy), tlx = cvt<T>((float)lx), tly = cvt<T>((float)ly);
             T wts[4] = {(tux - fx) * (tuy - fy), (tux - fx) * (fy - tly), (fx - tlx) * (tuy - fy), (fx - tlx) * (fy - tly)};
@@ -227,7 +230,10 @@ __global__ void __launch_bounds__(256) k_temporal_map(SceneDev<T> sc, FrameDev<T
             st.bm_extra = 0.f;
             T fx = g_fx - cvt<T>(xorwow_uniform(st));
             T fy = g_fy - cvt<T>(xorwow_uniform(st));
-            int lx = f2i((float)fx), ly = f2i((float)fy), ux = lx + 1, uy = ly + 1;
+            // f2i truncates toward zero as the reference's int() does: a position in (-1, 0) keeps lx = 0 and extrapolates
+            // (LPRT_OPT_FLOOR_REPROJECTION = 1: floor)
+            int lx = floor_taps ? (int)__builtin_floorf((float)fx) : f2i((float)fx), ly = floor_taps ? (int)__builtin_floorf((float)fy) : f2i((float)fy);
+            int ux = lx + 1, uy = ly + 1;
             int nx[4] = {lx, lx, ux, ux}, ny[4] = {ly, uy, ly, uy};
             T tux = cvt<T>((float)ux), tuy = cvt<T>((float)uy), tlx = cvt<T>((float)lx), tly = cvt<T>((float)ly);
             T wts[4] = {(tux - fx) * (tuy - fy), (tux - fx) * (fy - tly), (fx - tlx) * (tuy - fy), (fx - tlx) * (fy - tly)};
@@ -860,8 +866,8 @@ template <typename T> void launch_fill_gbuffer(hipStream_t st, const SceneDev<T>
     else
         hipLaunchKernelGGL((k_fill_gbuffer<T, false>), tile_grid(fb), dim3(256), 0, st, sc, fb, c);
 }
-template <typename T> void launch_temporal_map(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, uint32_t rng_d) {
-    hipLaunchKernelGGL(k_temporal_map<T>, grid_for(fb.win.npix()), dim3(256), 0, st, sc, fb, first ? 1 : 0, rng_d);
+template <typename T> void launch_temporal_map(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, uint32_t rng_d, bool floor_taps) {
+    hipLaunchKernelGGL(k_temporal_map<T>, grid_for(fb.win.npix()), dim3(256), 0, st, sc, fb, first ? 1 : 0, rng_d, floor_taps ? 1 : 0);
 }
 // tiles x sample slots of the batch
 template <typename T> static inline dim3 tile_grid_z(const FrameDev<T> &fb, uint32_t slots) { return dim3(tile_grid(fb).x, 1, slots); }
@@ -1000,7 +1006,7 @@ void launch_stream_rays(hipStream_t st, const SceneDev<T> &sc, const lprt_ray *r
     template void launch_spp_mean<T>(hipStream_t, const FrameDev<T> &, uint32_t, uint32_t, uint32_t);                  \
     template void launch_stream_rays<T>(hipStream_t, const SceneDev<T> &, const lprt_ray *, uint32_t, bool, bool, lprt_hit *, uint32_t *, Counters *); \
     template void launch_fill_gbuffer<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, Counters *);          \
-    template void launch_temporal_map<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, uint32_t);      \
+    template void launch_temporal_map<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, uint32_t, bool);      \
     template void launch_shade<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, const SampleBatch &);   \
     template void launch_trace_di<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, bool, bool, uint32_t, bool, Counters *, bool); \
     template void launch_trace_gi<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, uint32_t, Counters *);
