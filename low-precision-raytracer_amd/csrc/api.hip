@@ -324,9 +324,9 @@ template <typename T> struct Impl : CtxBase {
         fb.sc_position = carve_slots<V4<T>>(off, n);
         fb.gi_hit = carve_slots<GiHit<T>>(off, n);
         fb.vis = carve_slots<uint8_t>(off, n * LPRT_MAX_DIRECT_LIGHT);
-        fb.smp_color = carve_slots<float4>(off, n);
-        fb.smp_gi_colored = carve_slots<float4>(off, n);
-        fb.smp_gi_white = carve_slots<float4>(off, n);
+        fb.smp_color = carve_slots<V4<T>>(off, n);
+        fb.smp_gi_colored = carve_slots<V4<T>>(off, n);
+        fb.smp_gi_white = carve_slots<V4<T>>(off, n);
         off = (off + 255) & ~size_t(255);
     }
     void ensure_sample_slots(uint32_t slots) {

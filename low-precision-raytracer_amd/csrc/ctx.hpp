@@ -167,7 +167,7 @@ template <typename T> struct FrameDev {
     // leaves per sample goes to smp_* and k_spp_mean sums the slots in sample order (the float sums of the sample loop,
     // in the same order).
     uint32_t smp_stride, rng_stride;
-    float4 *smp_color, *smp_gi_colored, *smp_gi_white;
+    V4<T> *smp_color, *smp_gi_colored, *smp_gi_white; // DataT: the sample loop adds DataT values in f32, (float)(DataT) is exact
 };
 #define LPRT_MAX_SAMPLE_BATCH 8u
 // the view of one sample slot

@@ -506,7 +506,7 @@ struct ComposeArgs {
     uint32_t reuse_direct; // round 0 ran for sample 0 only (lprt_frame_settings.reuse_direct_light): its radiance is slot 0's
 };
 // write_clean_color (cuda.hpp:2170-2199) for pixel p of one sample slot, whose radiance of this round (`cur`) has just been
-// completed: the sample's three contributions go to the slot's smp_* planes (f32) and k_spp_mean sums the slots in sample
+// completed: the sample's three contributions go to the slot's smp_* planes (DataT, as computed) and k_spp_mean sums the slots in f32 in sample
 // order.  slot0: the frame planes of slot 0 (round 0's radiance under reuse_direct_light).
 template <typename T, bool FIRST>
 LPRT_DEV void compose_tail(const FrameDev<T> &fb, const FrameDev<T> &slot0, const ComposeArgs &ca, uint32_t p, V4<T> cur) {
@@ -521,9 +521,10 @@ LPRT_DEV void compose_tail(const FrameDev<T> &fb, const FrameDev<T> &slot0, cons
     } else if (ca.add_direct_out) {
         fc = fc + elemul(i1, xyz(m0));
     }
-    fb.smp_color[p] = make_float4((float)fc.x, (float)fc.y, (float)fc.z, 0.f);
-    fb.smp_gi_colored[p] = make_float4((float)colored.x, (float)colored.y, (float)colored.z, 0.f);
-    fb.smp_gi_white[p] = make_float4((float)white.x, (float)white.y, (float)white.z, 0.f);
+    const T zero = (T)0;
+    fb.smp_color[p] = mk4(fc.x, fc.y, fc.z, zero);
+    fb.smp_gi_colored[p] = mk4(colored.x, colored.y, colored.z, zero);
+    fb.smp_gi_white[p] = mk4(white.x, white.y, white.z, zero);
 }
 // The build-side spp mean: sample s of n accumulates in f32 in sample order; the last sample divides once and rounds once to
 // DataT (spp = 1 is exactly a reference frame).  One launch per batch of samples, after the batch's last stage.
@@ -535,7 +536,9 @@ template <typename T> __global__ void __launch_bounds__(256) k_spp_mean(FrameDev
     float4 ac = make_float4(0.f, 0.f, 0.f, 0.f), ag = ac, aw = ac;
     for (uint32_t z = 0; z < count; z++) {
         const size_t q = (size_t)z * fb.smp_stride + p;
-        const float4 c = fb.smp_color[q], g = fb.smp_gi_colored[q], w = fb.smp_gi_white[q];
+        const V4<T> ct = fb.smp_color[q], gt = fb.smp_gi_colored[q], wt = fb.smp_gi_white[q];
+        const float4 c = make_float4((float)ct.x, (float)ct.y, (float)ct.z, 0.f), g = make_float4((float)gt.x, (float)gt.y, (float)gt.z, 0.f),
+                     w = make_float4((float)wt.x, (float)wt.y, (float)wt.z, 0.f);
         if (first + z == 0u) {
             ac = c;
             ag = g;
