@@ -422,7 +422,12 @@ typedef enum {
                                      * writes NaN (the oracle reproduces it pixel for pixel).  1: floor() -- such a
                                      * position keeps the one tap inside the image at weight 1.  Every pixel whose history
                                      * position is not negative is unaffected.  LPRT_FLOOR_REPROJECTION */
-    LPRT_OPT_COUNT = 14
+    LPRT_OPT_STREAM_XCD = 14,       /* 1 (default): a ray stream's items are cut into 8 contiguous ranges (image bands) with a work
+                                     * counter each; workgroups that share an XCD (equal blockIdx % 8) drain one range first -- rays
+                                     * that start next to each other meet in one XCD's L2 -- and steal from the other ranges when
+                                     * theirs is empty.  0: one counter, batches go to whichever wave asks next.  Results never
+                                     * depend on it.  LPRT_STREAM_XCD */
+    LPRT_OPT_COUNT = 15
 } lprt_option;
 int lprt_set_option(lprt_ctx *ctx, lprt_option option, int value);
 int lprt_get_option(lprt_ctx *ctx, lprt_option option, int *value);

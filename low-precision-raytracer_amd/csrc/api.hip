@@ -80,7 +80,7 @@ struct CtxBase {
     uint32_t sample_first = 0, sample_rows = 0; // 0 rows: the whole window
     int next_phase = LPRT_PHASE_SAMPLE;
     // behaviour knobs (lprt_option): initialised from the environment once, in lprt_create; never read from it afterwards
-    int opts[LPRT_OPT_COUNT] = {-1, -1, 1, 0, 0, 1, 0, -1, 0, 12, 20, 0, (int)LPRT_MAX_SAMPLE_BATCH, 0};
+    int opts[LPRT_OPT_COUNT] = {-1, -1, 1, 0, 0, 1, 0, -1, 0, 12, 20, 0, (int)LPRT_MAX_SAMPLE_BATCH, 0, 1};
     void options_from_environment() {
         if (const char *w = std::getenv("LPRT_WIDE_WALK"))
             opts[LPRT_OPT_WIDE_WALK] = w[0] == '1' ? 1 : 0;
@@ -102,6 +102,8 @@ struct CtxBase {
             opts[LPRT_OPT_SAMPLE_BATCH] = std::max(1, std::min((int)LPRT_MAX_SAMPLE_BATCH, std::atoi(r)));
         if (const char *r = std::getenv("LPRT_FLOOR_REPROJECTION"))
             opts[LPRT_OPT_FLOOR_REPROJECTION] = r[0] == '1' ? 1 : 0;
+        if (const char *r = std::getenv("LPRT_STREAM_XCD"))
+            opts[LPRT_OPT_STREAM_XCD] = r[0] == '0' ? 0 : 1;
         if (const char *r = std::getenv("LPRT_STREAM_SCHED"))
             opts[LPRT_OPT_STREAM_SCHED] = r[0] == '1' ? 1 : 0;
         if (const char *r = std::getenv("LPRT_STREAM_WIDE_CLOSEST"))
@@ -403,9 +405,9 @@ template <typename T> struct Impl : CtxBase {
     // shadow rays walk deep BLAS trees two levels per step (trace.hpp); LPRT_OPT_WIDE_WALK overrides for A/B runs
     // GI / shadow rays as ray streams (stream.hpp): large scenes by default, LPRT_OPT_RAY_STREAM overrides
     bool ray_streams() const { return opts[LPRT_OPT_RAY_STREAM] < 0 ? geo.max_depth >= 6 : opts[LPRT_OPT_RAY_STREAM] != 0; }
-    DevBuf d_stream_counters; // one zeroed work counter per stream launch of a frame
+    DevBuf d_stream_counters; // LPRT_STREAM_COUNTER_WORDS zeroed words per stream launch of a frame: 8 work counters, one per 64-byte line
     uint32_t stream_launches = 0;
-    uint32_t *next_stream_counter() { return d_stream_counters.as<uint32_t>() + stream_launches++; }
+    uint32_t *next_stream_counter() { return d_stream_counters.as<uint32_t>() + LPRT_STREAM_COUNTER_WORDS * (size_t)stream_launches++; }
     bool wide_anyhit() const { return opts[LPRT_OPT_WIDE_WALK] < 0 ? geo.max_depth >= 6 : opts[LPRT_OPT_WIDE_WALK] != 0; }
     uint32_t jitter_d = 0; // d word of this frame's seed A, drawn in the sample phase, used by the temporal maps
     void render_phase(const lprt_frame_settings &fs, int phase) override {
@@ -448,7 +450,7 @@ template <typename T> struct Impl : CtxBase {
         // per-pixel kernel serves them better (atrium: 7.5 vs 12.2 ms per frame) unless streams are forced on
         const bool stream_round0 = streams && opts[LPRT_OPT_RAY_STREAM] == 1;
         if (streams) {
-            const size_t need = sizeof(uint32_t) * (3 * (size_t)((spp + batch_max - 1) / batch_max) + 1);
+            const size_t need = sizeof(uint32_t) * LPRT_STREAM_COUNTER_WORDS * (3 * (size_t)((spp + batch_max - 1) / batch_max) + 1);
             d_stream_counters.reserve(need);
             LPRT_HIP(hipMemsetAsync(d_stream_counters.ptr, 0, need, stream));
             stream_launches = 0;
@@ -740,6 +742,7 @@ template <typename T> struct Impl : CtxBase {
         sc.stream_refill_min = (uint32_t)opts[LPRT_OPT_STREAM_REFILL_MIN];
         sc.stream_node_min = (uint32_t)opts[LPRT_OPT_STREAM_NODE_MIN];
         sc.stream_sched = (uint32_t)opts[LPRT_OPT_STREAM_SCHED];
+        sc.stream_xcd = opts[LPRT_OPT_STREAM_XCD] ? 1u : 0u;
         sc.objects = d_objects.template as<ObjConst<T>>();
         sc.blas = geo.d_blas.template as<BlasInfo>();
         sc.blas_roots = geo.d_roots.template as<T>();
@@ -784,8 +787,8 @@ template <typename T> struct Impl : CtxBase {
         // closest-hit batches through the two-level walk (parity of that walk at hit-record level)
         const bool wide = find_any ? wide_anyhit() : opts[LPRT_OPT_WIDE_WALK] == 1;
         if (ray_streams()) { // the persistent traversal the frame kernels take in large scenes
-            d_stream_counters.reserve(sizeof(uint32_t) * 4);
-            LPRT_HIP(hipMemsetAsync(d_stream_counters.ptr, 0, sizeof(uint32_t), stream));
+            d_stream_counters.reserve(sizeof(uint32_t) * LPRT_STREAM_COUNTER_WORDS);
+            LPRT_HIP(hipMemsetAsync(d_stream_counters.ptr, 0, sizeof(uint32_t) * LPRT_STREAM_COUNTER_WORDS, stream));
             launch_stream_rays<T>(stream, scene_dev(), d_rays.as<lprt_ray>(), n, find_any != 0,
                                   find_any ? wide : (wide || opts[LPRT_OPT_STREAM_WIDE_CLOSEST] != 0), d_hits.as<lprt_hit>(),
                                   d_stream_counters.as<uint32_t>(), stage_counters(LPRT_STAGE_PRIMARY));

@@ -26,6 +26,7 @@ void launch_sample_texture(hipStream_t st, const Texture *textures, const float 
 
 // pipeline.hip
 // A batch of samples runs through each per-sample stage in ONE launch (FrameDev: sample slots): slot z holds sample first + z.
+#define LPRT_STREAM_COUNTER_WORDS 128u // per stream launch: work counter c of 8 at word 16 * c (stream.hpp)
 struct SampleBatch {
     uint32_t first, count;                    // count <= LPRT_MAX_SAMPLE_BATCH
     uint32_t rng_d[LPRT_MAX_SAMPLE_BATCH];    // d word of each slot's shade seed

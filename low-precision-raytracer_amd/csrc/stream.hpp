@@ -84,20 +84,41 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items, ui
     is.inscene_objid = is.inobject_offset = 0;
     is.bary = zero3<T>();
     const bool flat = sc.tlas_mode == 1u;
+    // XCD-local order (SceneDev::stream_xcd): range r of 8 covers the items [r * range, (r + 1) * range) -- whole batches, a band
+    // of the image -- and has its own counter; a wave starts with the range of its workgroup's XCD group (blockIdx % 8: the
+    // dispatcher deals workgroups round-robin over the XCDs) and moves on to the next range when a grant finds one drained.
+    // `ranges_left` only falls, every counter only grows: a wave is exhausted after at most 8 failed grants.
+    const uint32_t n_ranges = sc.stream_xcd ? 8u : 1u;
+    const uint32_t range = sc.stream_xcd ? (((n_items + 7u) / 8u + 63u) & ~63u) : n_items;
+    uint32_t ranges_tried = 0;
 
     for (;;) {
         // ---- prepare: when the ring has room for a batch, all 64 lanes fetch and scan one item each ---------------------
         if (!exhausted && head - tail <= LPRT_STREAM_RING - 64u) {
-            uint32_t base = 0;
-            if (lane == 0u)
-                base = atomicAdd(stream_counter, 64u);
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            if (base + 64u >= n_items)
-                exhausted = true; // wave-uniform: nothing is left behind this grant
+            uint32_t base = 0, limit = 0;
+            while (ranges_tried < n_ranges) {
+                const uint32_t r = ((blockIdx.x & 7u) + ranges_tried) & (n_ranges - 1u);
+                const uint32_t lo = r * range, len = lo < n_items ? (n_items - lo < range ? n_items - lo : range) : 0u;
+                uint32_t b = len; // an empty range: nothing to ask for
+                if (len != 0u) {
+                    if (lane == 0u)
+                        b = atomicAdd(stream_counter + 16u * r, 64u);
+                    b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+                }
+                if (b + 64u >= len)
+                    ranges_tried++; // wave-uniform: nothing is left in this range behind this grant
+                if (b < len) {
+                    base = lo + b;
+                    limit = lo + len;
+                    break;
+                }
+            }
+            if (ranges_tried >= n_ranges)
+                exhausted = true;
             PrepRay<T> pr;
             RayT<T> nray{zero3<T>(), zero3<T>()};
             pr.item = base + lane;
-            const bool ok = pr.item < n_items && src.load(pr.item, nray, pr.tmin, pr.tmax, pr.skip_vao, pr.skip_off);
+            const bool ok = pr.item < limit && src.load(pr.item, nray, pr.tmin, pr.tmax, pr.skip_vao, pr.skip_off);
             if (ok) {
                 if (COUNT)
                     cnt.rays++;

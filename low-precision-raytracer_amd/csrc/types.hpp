@@ -97,6 +97,7 @@ template <typename T> struct SceneDev {
     uint32_t axis_reject; // 1 (default): trace.hpp's stationary-axis rejection on; 0: the reference's plain slab test
     uint32_t stream_refill_min, stream_node_min; // ray-stream tunables (stream.hpp), lane counts
     uint32_t stream_sched;                       // 1: one phase per pass, the one most lanes wait for; 0: all phases every pass
+    uint32_t stream_xcd;                         // 1: eight item ranges with a counter each, drained XCD by XCD (stream.hpp); 0: one counter
     const ObjConst<T> *objects;
     // BLAS
     const BlasInfo *blas;

@@ -624,7 +624,7 @@ def test_render_phases_and_sample_rows_are_checked(cornell):
 def test_options_out_array_sizes_and_null_pointers_are_checked(cornell):
     import ctypes as C
     with lprt_amd.Renderer(32, 32, abi.F32) as r:
-        assert [r.get_option(n) for n in abi.OPTIONS] == [-1, -1, 1, 0, 0, 1, 0, -1, 0, 12, 20, 0, 8, 0]
+        assert [r.get_option(n) for n in abi.OPTIONS] == [-1, -1, 1, 0, 0, 1, 0, -1, 0, 12, 20, 0, 8, 0, 1]
         r.set_option("wide_walk", 1)
         assert r.get_option("wide_walk") == 1
         with pytest.raises(lprt_amd.LprtError, match="out of range"):
