@@ -41,12 +41,25 @@ LPRT_DEV bool stream_box(const T *lo, const T *hi, const RaySlab<T> &rs, float b
 // ~30 instructions per box: done by the few lanes that happen to be idle it cost more than the refill saved), parked in a
 // per-wave LDS ring, and handed to lanes as they fall idle -- a pop is a dozen instructions, so a lane waits for work for
 // one iteration of the loop, not until three quarters of the wave have run dry.
-template <typename T> struct PrepRay { // 64 B (f32) / 48 B (f16)
+template <typename T> struct PrepRay { // 48 B (f32) / 32 B (f16)
     V3<T> o, d;
     T tmin, tmax;
     uint32_t skip_vao, skip_off, item, cand; // cand: candidate-instance bits (flat scan) or "the TLAS root box is hit" (tree)
+};
+// What a lane needs of its ray BETWEEN instances only -- the world-space ray and its reciprocals, the skipped mesh, the item
+// number, the state of the top-level walk -- lives in a per-lane LDS record, not in registers: the walk inside an instance
+// (node and leaf phases, where the time goes) never touches it.  Held in registers, these ~15 words were what the compiler
+// spilled to scratch at the 128-register budget (64 B per lane in k_stream_gi): 3 GB of scratch written and re-read per launch
+// through the same L2 that should hold the scene (WRITE_SIZE 2.9 GB for a kernel whose results are 0.27 GB), and 2 MB of
+// scratch lines per XCD competing with the BVH for 4 MB of L2.
+template <typename T> struct WorldRay { // 60 B (f32) / 48 B (f16) per lane
+    V3<T> o, d;
     float ix, iy, iz;
     uint32_t slow;
+    uint32_t skip_vao, item;
+    uint32_t top;   // flat scan: candidate-instance bits still to visit; tree: the TLAS node the walk stands on
+    uint32_t tpend; // tree: deferred siblings, one bit per level
+    uint32_t tcl;   // tree: depth | leaf cursor << 8 | walk alive << 16
 };
 #ifndef LPRT_STREAM_RING
 #define LPRT_STREAM_RING 128u // prepared rays a wave can park (power of two, >= 128: a batch of 64 is prepared when 64 slots are free)
@@ -56,20 +69,15 @@ template <typename T> struct PrepRay { // 64 B (f32) / 48 B (f16)
 template <typename T, bool ANY, bool COUNT, bool WIDE, typename Src>
 LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items, uint32_t *stream_counter, Cnt<COUNT> &cnt) {
     __shared__ PrepRay<T> s_ring[4][LPRT_STREAM_RING];
+    __shared__ WorldRay<T> s_world[256];
     PrepRay<T> *ring = s_ring[threadIdx.x >> 6];
+    WorldRay<T> &world = s_world[threadIdx.x];
     const uint32_t lane = threadIdx.x & 63u;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     bool has_ray = false, in_obj = false, exhausted = false;
     uint32_t head = 0, tail = 0; // ring positions (wave-uniform): [tail, head) are parked
-    uint32_t item = 0;
-    // world-space ray
-    RayT<T> wray{zero3<T>(), zero3<T>()};
     T tmin = (T)0, tmax = (T)0;
-    uint32_t skip_vao = 0xffffffffu, skip_off = 0;
-    // top level: candidate bits (flat scan, <= 32 instances) or the TLAS walk's (node, depth, pending) + leaf cursor
-    uint32_t cand = 0, ti = 1, tc = 0, tpend = 0, tleaf = 0;
-    bool tlas_live = false;
-    RaySlab<T> wrs{};
+    uint32_t skip_off = 0;
     // current instance
     RayT<T> lray{zero3<T>(), zero3<T>()};
     RaySlab<T> lrs{};
@@ -125,10 +133,6 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items, ui
                 const RaySlab<T> nrs = make_slab(nray, sc.axis_reject);
                 pr.o = nray.o;
                 pr.d = nray.d;
-                pr.ix = nrs.ix;
-                pr.iy = nrs.iy;
-                pr.iz = nrs.iz;
-                pr.slow = nrs.slow;
                 pr.cand = 0;
                 if (sc.n_objects != 0u) {
                     if (flat) {
@@ -163,26 +167,21 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items, ui
                 const uint32_t rank = (uint32_t)__builtin_popcountll(idle & lt_mask);
                 if (!has_ray && rank < n_take) {
                     const PrepRay<T> pr = ring[(tail + rank) & (LPRT_STREAM_RING - 1u)];
-                    item = pr.item;
-                    wray.o = pr.o;
-                    wray.d = pr.d;
+                    const RaySlab<T> prs = make_slab(RayT<T>{pr.o, pr.d}, sc.axis_reject); // the reciprocals again: cheaper than parking them
+                    world.o = pr.o;
+                    world.d = pr.d;
+                    world.ix = prs.ix;
+                    world.iy = prs.iy;
+                    world.iz = prs.iz;
+                    world.slow = prs.slow;
+                    world.skip_vao = pr.skip_vao;
+                    world.item = pr.item;
+                    world.top = flat ? pr.cand : 1u;
+                    world.tpend = 0u;
+                    world.tcl = (!flat && pr.cand != 0u) ? (1u << 16) : 0u;
                     tmin = pr.tmin;
                     tmax = pr.tmax;
-                    skip_vao = pr.skip_vao;
                     skip_off = pr.skip_off;
-                    wrs.o = pr.o;
-                    wrs.ix = pr.ix;
-                    wrs.iy = pr.iy;
-                    wrs.iz = pr.iz;
-                    wrs.slow = pr.slow;
-                    wrs.reject = sc.axis_reject;
-                    wrs.par = sc.axis_reject ? pr.slow : 0u;
-                    cand = flat ? pr.cand : 0u;
-                    tlas_live = !flat && pr.cand != 0u;
-                    ti = 1;
-                    tc = 0;
-                    tpend = 0;
-                    tleaf = 0;
                     has_ray = true;
                     in_obj = false;
                     is.hit = false;
@@ -216,13 +215,27 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items, ui
         if (run_entry && has_ray && !in_obj) {
             cnt.step(0);
             uint32_t k = 0xffffffffu; // slot of the next instance to enter
+            // the world-space ray and the top-level walk come out of the lane's LDS record and go back into it below
+            RayT<T> wray{world.o, world.d};
+            RaySlab<T> wrs{};
+            wrs.o = wray.o;
+            wrs.ix = world.ix;
+            wrs.iy = world.iy;
+            wrs.iz = world.iz;
+            wrs.slow = world.slow;
+            wrs.reject = sc.axis_reject;
+            wrs.par = sc.axis_reject ? wrs.slow : 0u;
             if (!(ANY && is.hit)) {
                 if (flat) {
+                    uint32_t cand = world.top;
                     if (cand) {
                         k = (uint32_t)__builtin_ctz(cand);
                         cand &= cand - 1u;
+                        world.top = cand;
                     }
                 } else {
+                    uint32_t ti = world.top, tpend = world.tpend, tc = world.tcl & 255u, tleaf = (world.tcl >> 8) & 255u;
+                    bool tlas_live = (world.tcl >> 16) != 0u;
                     // resume the TLAS walk (cast_ray's tree loop, trace.hpp) until it yields an instance whose world box passes
                     while (tlas_live && k == 0xffffffffu) {
                         if (tc < sc.tlas_depth) {
@@ -266,10 +279,13 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items, ui
                         tc = d;
                         tleaf = 0;
                     }
+                    world.top = ti;
+                    world.tpend = tpend;
+                    world.tcl = tc | (tleaf << 8) | (tlas_live ? (1u << 16) : 0u);
                 }
             }
             if (k == 0xffffffffu) {
-                src.store(item, is); // the ray is done
+                src.store(world.item, is); // the ray is done
                 has_ray = false;
             } else {
                 const ObjHead<T> ob = load_obj_head(sc.objrecs + k); // one round trip; the matrix only when it is one
@@ -292,7 +308,7 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items, ui
                         n_tris = ob.n_tris;
                         tri_base = ob.tri_base;
                         obj_id = ob.inscene_objid;
-                        skip_here = ob.vao_index == skip_vao;
+                        skip_here = ob.vao_index == world.skip_vao;
                         i = 1;
                         c = 0;
                         pend = 0;
