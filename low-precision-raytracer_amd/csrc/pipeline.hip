@@ -668,6 +668,9 @@ __global__ void __launch_bounds__(256, LPRT_CLOSEST_WAVES) k_trace_gi(SceneDev<T
 static inline dim3 grid_for(uint32_t n) { return dim3((n + 255) / 256); }
 
 // ---- ray streams (stream.hpp): persistent traversal kernels + the per-pixel stages that follow them ----------------------
+#ifndef LPRT_STREAM_DI_WAVES
+#define LPRT_STREAM_DI_WAVES LPRT_STREAM_WAVES // the any-hit stream (no hit record, no barycentrics) needs fewer registers
+#endif
 #ifndef LPRT_STREAM_WAVES
 #define LPRT_STREAM_WAVES 4 // waves per SIMD the stream kernels are compiled for
 #endif
@@ -783,7 +786,7 @@ __global__ void __launch_bounds__(256, LPRT_STREAM_WAVES) k_stream_gi(SceneDev<T
     flush_counters<COUNT>(cnt, counters);
 }
 template <typename T, bool FIRST, bool COUNT, bool WIDE>
-__global__ void __launch_bounds__(256, LPRT_STREAM_WAVES) k_stream_di(SceneDev<T> sc, FrameDev<T> fb, uint32_t n_slots, uint32_t slots, uint32_t n_items,
+__global__ void __launch_bounds__(256, LPRT_STREAM_DI_WAVES) k_stream_di(SceneDev<T> sc, FrameDev<T> fb, uint32_t n_slots, uint32_t slots, uint32_t n_items,
                                                                        uint32_t *counter, Counters *counters) {
     Cnt<COUNT> cnt;
     DiSource<T, FIRST> src{fb, n_slots, slots};
