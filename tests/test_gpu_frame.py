@@ -155,23 +155,25 @@ def test_atrium_frames_with_per_frame_rebuild_match_oracle_ray_by_ray(sponza, pr
 def test_launch_structure_never_changes_a_frame(scene_name, W, H, prec):
     """How the rays are launched is a matter of speed only.  Ray streams (csrc/stream.hpp: persistent waves that refill
     finished lanes; flat instance scan on the atrium and Cornell, the TLAS tree walk on the 150-instance field) against one
-    ray per lane in the fused kernels, and 1 / 2 / 8 samples per launch (sample slots, k_spp_mean in sample order): three
+    ray per lane in the fused kernels, one stream counter against eight XCD-local ranges, and 1 / 2 / 8 samples per launch
+    (sample slots, k_spp_mean in sample order): three
     frames at 3 spp come out bit-identical -- display image, the last sample's radiance of both rounds, the denoiser's
     input -- for every combination, and so do the ray counts."""
     sc = scenes.SCENES[scene_name]()
     outs = {}
-    for stream, batch in ((0, 1), (0, 8), (1, 1), (1, 2), (1, 8), (-1, 8)):
+    for stream, batch, xcd in ((0, 1, 1), (0, 8, 1), (1, 1, 1), (1, 2, 0), (1, 8, 1), (1, 8, 0), (-1, 8, 1)):
         with lprt_amd.Renderer(W, H, prec) as r:
             r.set_option("ray_stream", stream)
             r.set_option("sample_batch", batch)
+            r.set_option("stream_xcd", xcd)  # one work counter, or eight item ranges drained XCD group by XCD group
             r.load_scene(sc)
             r.enable_counters(True)
             for _ in range(3):
                 r.set_scene(sc)
                 r.render(abi.default_settings(spp=3))
-            outs[(stream, batch)] = [r.read(n) for n in ("OUTPUT", "INTENSITY0", "INTENSITY1", "RAW_GI_COLORED", "RAW_COLOR", "GI_DIRECTION")] + \
+            outs[(stream, batch, xcd)] = [r.read(n) for n in ("OUTPUT", "INTENSITY0", "INTENSITY1", "RAW_GI_COLORED", "RAW_COLOR", "GI_DIRECTION")] + \
                                     [np.array([r.stage_counters(st)["rays"] for st in ("primary", "trace_di1", "trace_gi", "trace_di2")])]
-    first = outs[(0, 1)]
+    first = outs[(0, 1, 1)]
     for key, got in outs.items():
         for a, b in zip(first, got):
             assert np.array_equal(a, b, equal_nan=True), key
