@@ -586,16 +586,18 @@ __global__ void __launch_bounds__(256, LPRT_ANYHIT_WAVES) k_trace_di(SceneDev<T>
             const V3<T> source = xyz(FIRST ? fb.g_position[p] : fb.sc_position[p]);
             const uint2 skip = fb.skips[p];
             V3<T> fc = zero3<T>(); // accumulate_di_light: final_color = {} ; += di_intensity[4p+i]
-            for (uint32_t i = 0; i < LPRT_MAX_DIRECT_LIGHT; i++) {
-                V3<T> di = zero3<T>();
-                if (mask & (1u << i)) {
-                    const V4<T> dm = fb.lc_dir_maxt[i * npix + p];
-                    const V3<T> mm = xyz(fb.lc_multiplier[i * npix + p]);
-                    RayT<T> ray{source, xyz(dm)};
-                    Isect<T> is = cast_ray<T, true, COUNT, WIDE>(sc, ray, skip.x, skip.y, cvt<T>(ray_moveforward_t<T>()), dm.w, cnt);
-                    di = (is.hit ? zero : one) * mm;
-                }
-                fc = fc + di;
+            // Each lane walks ITS OWN active slots in slot order (the j-th pass serves every lane's j-th light) instead of all
+            // lanes stepping through slots 0..3 together: a pass is as full as the lanes' light COUNTS allow, not as the
+            // agreement of their masks (atrium: shadow rays of round 0 6.66 -> 6.53 ms, 4.99 -> 4.94 in half).  The per-pixel
+            // sum keeps its order; the slots a pixel does not use contributed +0, and x + (+0) == x for every x this sum can hold
+            // (it starts at +0, so it is never -0).
+            for (uint32_t m = mask; m; m &= m - 1u) {
+                const uint32_t i = (uint32_t)__builtin_ctz(m);
+                const V4<T> dm = fb.lc_dir_maxt[i * npix + p];
+                const V3<T> mm = xyz(fb.lc_multiplier[i * npix + p]);
+                RayT<T> ray{source, xyz(dm)};
+                Isect<T> is = cast_ray<T, true, COUNT, WIDE>(sc, ray, skip.x, skip.y, cvt<T>(ray_moveforward_t<T>()), dm.w, cnt);
+                fc = fc + (is.hit ? zero : one) * mm;
             }
             cur = mk4(cur.x + fc.x, cur.y + fc.y, cur.z + fc.z, zero);
             intensity[p] = cur;
