@@ -58,12 +58,12 @@ template <typename T> LPRT_DEV T specular_brdf(V3<T> V, V3<T> H, V3<T> L, V3<T> 
     T one = (T)1;
     T div1 = aNL + tsqrt(tmax(zero, a2 + (one - a2) * aNL * aNL));
     T div2 = aNV + tsqrt(tmax(zero, a2 + (one - a2) * aNV * aNV));
-    T D = tdiv(a2, cvt<T>((float)LPRT_PI_D) * tpow(NdotH * NdotH * (a2 - one) + one, (T)2));
+    T D = tdiv(a2, cvt<T>((float)LPRT_PI_D) * tpow2(NdotH * NdotH * (a2 - one) + one));
     return tdiv(tdiv(D, div1), div2);
 }
 template <typename T> LPRT_DEV T fresnel_pow5(V3<T> V, V3<T> H) {
     T VdotH = dot(V, H);
-    return tpow(tmax((T)0, (T)1 - tabs(VdotH)), (T)5);
+    return tpow5(tmax((T)0, (T)1 - tabs(VdotH)));
 }
 template <typename T> LPRT_DEV Brdf<T> material_brdf(T metallic, T roughness, V3<T> V, V3<T> L, V3<T> N) { // bsdf.hpp:57-97
     T zero = (T)0, one = (T)1;
