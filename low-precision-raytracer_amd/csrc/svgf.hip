@@ -541,8 +541,12 @@ __global__ void __launch_bounds__(256) k_finalize(SceneDev<T> sc, FrameDev<T> fb
     V4<T> o4 = mk4(out.x, out.y, out.z, zero);
     fb.color_inprogress[p] = o4;
     taa_next[p] = o4; // history for the next frame (imgui_window.cu:260-262), double-buffered
+    // display gamma x^(1/2.2) (write_to_surface2d) as exp2(log2(x) / 2.2) on the transcendental unit: relative error ~1e-6 of a
+    // value that becomes 8 bits on screen (the device powf is ~170 instructions per channel; CUDA's, which the reference
+    // calls, is specified to 4 ulp); 0 -> 0, 1 -> 1, inf -> inf, negative or NaN -> NaN as with powf
     const float ig = 1 / 2.2f;
-    const float4 rgba = make_float4(::powf((float)out.x, ig), ::powf((float)out.y, ig), ::powf((float)out.z, ig), 1.f);
+    const float4 rgba = make_float4(__builtin_amdgcn_exp2f(__builtin_amdgcn_logf((float)out.x) * ig), __builtin_amdgcn_exp2f(__builtin_amdgcn_logf((float)out.y) * ig),
+                                    __builtin_amdgcn_exp2f(__builtin_amdgcn_logf((float)out.z) * ig), 1.f);
     fb.output[p] = rgba;
     if (ext_out) { // this rank's rows of the gathered frame (sharded rendering)
         const uint32_t row = fb.win.row_begin + p / fb.win.W;
