@@ -45,14 +45,18 @@ struct TopVectors {
 // blockIdx.z = seed of a batch: src / dst planes of seed z start at z * src_seed_stride / z * dst_seed_stride.
 constexpr int RNG_S = 128; // sources per block
 LPRT_DEV uint32_t xor_and(uint32_t acc, uint32_t col, uint32_t mask) { return __builtin_amdgcn_bitop3_b32(acc, col, mask, 0x78); }
-template <int TOP>
+// JW = matrices per wave: 4 for the last level (a column read serves eight matvecs' worth of stores per lane), 1 for the two
+// small upper levels, whose few sources leave most lanes idle and whose cost is the LATENCY of one wave working through its
+// matrices one after the other -- three dependent launches of ~40 us each were a fixed 120 us per frame, 22 % of the frame
+// of a rank that renders an eighth of the image.
+template <int TOP, int JW>
 __global__ void __launch_bounds__(256, 4) k_rng_expand(const XorMat *__restrict__ P, const uint32_t *__restrict__ src, TopBatch topb, TopVectors top1,
                                                        uint32_t n_src, uint32_t src_stride, uint32_t src_seed_stride, uint32_t *__restrict__ dst,
                                                        uint32_t dst_first, uint32_t dst_count, uint32_t dst_stride, uint32_t dst_seed_stride) {
     __shared__ uint4 mat[4][160 * 2]; // [wave][column][8 words]
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t sA = blockIdx.x * RNG_S + lane, sB = sA + 64;
-    const uint32_t jbase = blockIdx.y * 16;
+    const uint32_t jbase = blockIdx.y * (4 * JW);
     const uint32_t z = blockIdx.z;
     src += (size_t)z * src_seed_stride;
     dst += (size_t)z * dst_seed_stride;
@@ -63,10 +67,10 @@ __global__ void __launch_bounds__(256, 4) k_rng_expand(const XorMat *__restrict_
         if (sB < n_src)
             vb[k] = TOP == 2 ? topb.v[z][k][sB & 15] : (TOP == 1 ? top1.v[k][sB & 63] : src[k * src_stride + sB]);
     }
-    uint32_t ra[5][4], rb[5][4]; // [state word][j of this wave]
+    uint32_t ra[5][JW], rb[5][JW]; // [state word][j of this wave]
 #pragma unroll
-    for (uint32_t jj = 0; jj < 4; jj++) {
-        const uint32_t jl = wave * 4 + jj; // 0..15 within the block
+    for (uint32_t jj = 0; jj < JW; jj++) {
+        const uint32_t jl = wave * JW + jj; // 0 .. 4 JW - 1 within the block
         const uint4 *m = reinterpret_cast<const uint4 *>(P + jbase + jl);
         for (uint32_t q = lane; q < 320; q += 64)
             mat[wave][q] = m[q];
@@ -107,17 +111,23 @@ __global__ void __launch_bounds__(256, 4) k_rng_expand(const XorMat *__restrict_
         const uint32_t ss = half == 0 ? sA : sB;
         if (ss >= n_src)
             continue;
-        const uint32_t n0 = ss * 64 + jbase + wave * 4;
-        const bool inside = n0 >= dst_first && n0 - dst_first + 4u <= dst_count;
-        if (inside && planes_aligned && ((n0 - dst_first) & 3u) == 0u) {
+        const uint32_t n0 = ss * 64 + jbase + wave * JW;
+        const bool inside = n0 >= dst_first && n0 - dst_first + (uint32_t)JW <= dst_count;
+        if (JW == 4 && inside && planes_aligned && ((n0 - dst_first) & 3u) == 0u) {
 #pragma unroll
             for (int k = 0; k < 5; k++) {
                 const uint32_t *r = half == 0 ? ra[k] : rb[k];
-                *reinterpret_cast<uint4 *>(dst + (size_t)k * dst_stride + (n0 - dst_first)) = make_uint4(r[0], r[1], r[2], r[3]);
+                *reinterpret_cast<uint4 *>(dst + (size_t)k * dst_stride + (n0 - dst_first)) = make_uint4(r[0], r[JW > 1 ? 1 : 0], r[JW > 2 ? 2 : 0], r[JW > 3 ? 3 : 0]);
+            }
+        } else if (JW == 2 && inside && planes_aligned && ((n0 - dst_first) & 1u) == 0u) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const uint32_t *r = half == 0 ? ra[k] : rb[k];
+                *reinterpret_cast<uint2 *>(dst + (size_t)k * dst_stride + (n0 - dst_first)) = make_uint2(r[0], r[JW > 1 ? 1 : 0]);
             }
         } else {
 #pragma unroll
-            for (uint32_t jj = 0; jj < 4; jj++) {
+            for (uint32_t jj = 0; jj < JW; jj++) {
                 const uint32_t n = n0 + jj;
                 if (n < dst_first || n - dst_first >= dst_count)
                     continue;
@@ -265,12 +275,12 @@ void RngStore::generate(hipStream_t st, const uint64_t *seeds, uint32_t n_seeds,
             }
         }
         if (n3 <= 16)
-            hipLaunchKernelGGL(k_rng_expand<2>, dim3((n3 + RNG_S - 1) / RNG_S, 4, batch), dim3(256), 0, st, mats + 128, (const uint32_t *)nullptr, topb, top1, n3,
+            hipLaunchKernelGGL((k_rng_expand<2, 1>), dim3((n3 + RNG_S - 1) / RNG_S, 16, batch), dim3(256), 0, st, mats + 128, (const uint32_t *)nullptr, topb, top1, n3,
                                0u, 0u, d_w2.as<uint32_t>(), 0u, w2_stride, w2_stride, 5 * w2_stride);
         else
-            hipLaunchKernelGGL(k_rng_expand<1>, dim3((n3 + RNG_S - 1) / RNG_S, 4, batch), dim3(256), 0, st, mats + 128, (const uint32_t *)nullptr, topb, top1, n3,
+            hipLaunchKernelGGL((k_rng_expand<1, 1>), dim3((n3 + RNG_S - 1) / RNG_S, 16, batch), dim3(256), 0, st, mats + 128, (const uint32_t *)nullptr, topb, top1, n3,
                                0u, 0u, d_w2.as<uint32_t>(), 0u, w2_stride, w2_stride, 5 * w2_stride);
-        hipLaunchKernelGGL(k_rng_expand<0>, dim3((n2 + RNG_S - 1) / RNG_S, 4, batch), dim3(256), 0, st, mats + 64, d_w2.as<uint32_t>(), topb, top1, n2, w2_stride,
+        hipLaunchKernelGGL((k_rng_expand<0, 1>), dim3((n2 + RNG_S - 1) / RNG_S, 16, batch), dim3(256), 0, st, mats + 64, d_w2.as<uint32_t>(), topb, top1, n2, w2_stride,
                            5 * w2_stride, d_w1.as<uint32_t>(), 0u, w1_stride, w1_stride, 5 * w1_stride);
         // last level only for the L1 vectors that cover a seed's pixel range: one launch per range present in the batch
         for (int part = 0; part < 2; part++) {
@@ -282,9 +292,19 @@ void RngStore::generate(hipStream_t st, const uint64_t *seeds, uint32_t n_seeds,
                 continue;
             const uint32_t s_begin = f / 64, s_end = (f + c + 63) / 64;
             uint32_t *out = part == 0 ? planes + (size_t)z0 * 5 * count : planes + (size_t)n_head * 5 * count + (size_t)(z0 - n_head) * 5 * count2;
-            hipLaunchKernelGGL(k_rng_expand<0>, dim3((s_end - s_begin + RNG_S - 1) / RNG_S, 4, z1 - z0), dim3(256), 0, st, mats,
-                               d_w1.as<uint32_t>() + (size_t)(z0 - done) * 5 * w1_stride + s_begin, topb, top1, s_end - s_begin, w1_stride, 5 * w1_stride, out,
-                               f - s_begin * 64, c, c, 5 * c);
+            // matrices per wave: as many (up to 4: wider stores, fewer matrix stagings) as still leave the chip a full set of
+            // workgroups -- a strip's launch is a fraction of one and then costs the latency of a wave's serial matvecs
+            const uint32_t bx = (s_end - s_begin + RNG_S - 1) / RNG_S, nz = z1 - z0;
+            const uint32_t *srcp = d_w1.as<uint32_t>() + (size_t)(z0 - done) * 5 * w1_stride + s_begin;
+            if (bx * 4u * nz >= 768u)
+                hipLaunchKernelGGL((k_rng_expand<0, 4>), dim3(bx, 4, nz), dim3(256), 0, st, mats, srcp, topb, top1, s_end - s_begin, w1_stride, 5 * w1_stride, out,
+                                   f - s_begin * 64, c, c, 5 * c);
+            else if (bx * 8u * nz >= 768u)
+                hipLaunchKernelGGL((k_rng_expand<0, 2>), dim3(bx, 8, nz), dim3(256), 0, st, mats, srcp, topb, top1, s_end - s_begin, w1_stride, 5 * w1_stride, out,
+                                   f - s_begin * 64, c, c, 5 * c);
+            else
+                hipLaunchKernelGGL((k_rng_expand<0, 1>), dim3(bx, 16, nz), dim3(256), 0, st, mats, srcp, topb, top1, s_end - s_begin, w1_stride, 5 * w1_stride, out,
+                                   f - s_begin * 64, c, c, 5 * c);
         }
         done += batch;
     }
