@@ -542,8 +542,18 @@ template <typename T> struct Impl : CtxBase {
             const bool always_test = opts[LPRT_OPT_SVGF_ALWAYS_TEST] != 0;
             stage(LPRT_STAGE_SVGF_TEMPORAL, [&] { launch_temporal_color<T>(stream, fb, fs.svgf_color_mix_weight, fs.svgf_moments_mix_weight, always_test); });
             stage(LPRT_STAGE_SVGF_MOMENTS, [&] { launch_moments<T>(stream, fb, fs.svgf_moments_mix_weight); });
+            // the rows the frame's consumers read: the strip this context writes out (lprt_set_output_target), else its window
+            uint32_t used_lo = 0, used_hi = win.rows();
+            if (ext_out && ext_rows != 0) {
+                used_lo = std::max(ext_first_row, win.row_begin) - win.row_begin;
+                used_hi = std::min(ext_first_row + ext_rows, win.row_end) - win.row_begin;
+                if (used_hi <= used_lo) {
+                    used_lo = 0;
+                    used_hi = win.rows();
+                }
+            }
             for (int level = 0; level < 5; level++)
-                stage(LPRT_STAGE_SVGF_WAVELET, [&] { launch_wavelet<T>(stream, fb, level, always_test); });
+                stage(LPRT_STAGE_SVGF_WAVELET, [&] { launch_wavelet<T>(stream, fb, level, always_test, used_lo, used_hi); });
             // moments history for the next frame: swap instead of the reference's (short) memcpy (DEVIATION Q8)
             for (int l = 0; l < 2; l++) {
                 std::swap(fb.lobe[l].miu1_hist, fb.lobe[l].miu1_cur);

@@ -59,7 +59,7 @@ void launch_stream_rays(hipStream_t st, const SceneDev<T> &sc, const lprt_ray *r
 template <typename T> void launch_depth_gradient(hipStream_t st, const FrameDev<T> &fb);
 template <typename T> void launch_temporal_color(hipStream_t st, const FrameDev<T> &fb, float color_w, float moments_w, bool always_test); // + the moments of pixels with >= 4 frames of history
 template <typename T> void launch_moments(hipStream_t st, const FrameDev<T> &fb, float moments_w);
-template <typename T> void launch_wavelet(hipStream_t st, const FrameDev<T> &fb, int level, bool always_test);
+template <typename T> void launch_wavelet(hipStream_t st, const FrameDev<T> &fb, int level, bool always_test, uint32_t row_lo, uint32_t row_hi);
 template <typename T>
 void launch_finalize(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, const V4<T> *gi_colored, const V4<T> *gi_white, V4<T> *taa_next,
                      bool add_colored, bool add_white, bool demodulate, float taa_w, float4 *ext_out, uint32_t ext_first_row, uint32_t ext_rows);

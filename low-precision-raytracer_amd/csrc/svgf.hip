@@ -324,7 +324,7 @@ constexpr int WV_BX = 64;
 template <typename T> struct WvRows { static constexpr int value = sizeof(T) == 4 ? LPRT_WV_BY32 : LPRT_WV_BY16; };
 template <typename T, int STRIDE>
 __global__ void __launch_bounds__(WV_BX * WvRows<T>::value) k_wavelet(FrameDev<T> fb, const V4<T> *in0, V4<T> *out0, const V4<T> *in1, V4<T> *out1, const T *vin0, T *vout0,
-                                                 const T *vin1, T *vout1, int always_test) {
+                                                 const T *vin1, T *vout1, int always_test, int lat0, int row_hi) {
     constexpr int WV_BY = WvRows<T>::value, WV_THREADS = WV_BX * WV_BY;
     constexpr int TW = WV_BX + 4 * STRIDE, TH = WV_BY + 4;
     // fp32 at strides 8 and 16: four staged planes (56 B per texel) leave room for only 3 / 2 workgroups per CU, and
@@ -338,7 +338,9 @@ __global__ void __launch_bounds__(WV_BX * WvRows<T>::value) k_wavelet(FrameDev<T
     const int tx = (int)(threadIdx.x % WV_BX), ty = (int)(threadIdx.x / WV_BX);
     const int oy = (int)(blockIdx.y % STRIDE), by = (int)(blockIdx.y / STRIDE);
     const int x0 = (int)blockIdx.x * WV_BX - 2 * STRIDE; // image x of tile column 0
-    const int r0 = WV_BY * by - 2;                        // lattice row of tile row 0
+    // lat0 / row_hi: the rows this launch has to produce start at lattice row lat0 of every phase and end before window row
+    // row_hi (launch_wavelet: a rank's strip needs level l only within the reach of the levels after it)
+    const int r0 = lat0 + WV_BY * by - 2;                 // lattice row of tile row 0
     // in single precision the one-test form measured 2 % slower than the tested one (0.649 vs 0.633 ms): half only
     constexpr bool FAST = LDS_COLOR && (sizeof(T) == 2 || LPRT_WV_FAST32);
     if (FAST) {
@@ -370,8 +372,8 @@ __global__ void __launch_bounds__(WV_BX * WvRows<T>::value) k_wavelet(FrameDev<T
     // workgroup-uniform: with every staged sample finite, a tap needs one test (its own weight) instead of six, both
     // weight sums coincide and colour + variance accumulate as two packed pairs
     const bool all_finite = FAST && !always_test && s_nonfinite == 0u;
-    const int px = (int)blockIdx.x * WV_BX + tx, py = oy + STRIDE * (WV_BY * by + ty);
-    if (px >= W || py >= R)
+    const int px = (int)blockIdx.x * WV_BX + tx, py = oy + STRIDE * (lat0 + WV_BY * by + ty);
+    if (px >= W || py >= row_hi)
         return;
     const uint32_t p = (uint32_t)(py * W + px);
     const int cx = tx + 2 * STRIDE, cy = ty + 2; // tile coordinates of the centre
@@ -626,19 +628,23 @@ template <typename T> void launch_moments(hipStream_t st, const FrameDev<T> &fb,
 }
 // level = 0..4 -> stride 1,2,4,8,16.  Buffer rotation (cuda.hpp:1678-1710 with cv_c in the role of color_inout, which
 // holds the integrated colour): L1 c->b (b = next frame's history), L2 b->a, L3 a->c, L4 c->a, L5 a->c; result in cv_c.
-template <typename T> void launch_wavelet(hipStream_t st, const FrameDev<T> &fb, int level, bool always_test) {
-    const uint32_t stride = 1u << level;
-    const uint32_t lattice_rows = (fb.win.rows() + stride - 1) / stride; // per phase (upper bound)
+// row_lo / row_hi: window rows whose results the rest of the frame uses (the whole window, or the strip a rank owns): level l
+// is needed within 64 - 2^(l+2) rows of them -- the taps of the levels after it -- and nowhere else.
+template <typename T> void launch_wavelet(hipStream_t st, const FrameDev<T> &fb, int level, bool always_test, uint32_t row_lo, uint32_t row_hi) {
+    const uint32_t stride = 1u << level, reach = 64u - (4u << level), R = fb.win.rows();
+    const uint32_t lo = row_lo > reach ? row_lo - reach : 0u, hi = std::min(R, row_hi + reach);
+    const uint32_t lat0 = lo / stride;                                   // the same first lattice row for every phase
+    const uint32_t lattice_rows = (hi - lat0 * stride + stride - 1) / stride; // per phase (upper bound)
     constexpr int WV_BY = WvRows<T>::value;
     const dim3 g((fb.win.W + WV_BX - 1) / WV_BX, stride * ((lattice_rows + WV_BY - 1) / WV_BY)), b(WV_BX * WV_BY);
     const SvgfLobe<T> &a = fb.lobe[0], &w = fb.lobe[1];
     const int at = always_test ? 1 : 0;
     switch (level) {
-    case 0: hipLaunchKernelGGL((k_wavelet<T, 1>), g, b, 0, st, fb, a.cv_c, a.cv_b, w.cv_c, w.cv_b, a.var_c, a.var_b, w.var_c, w.var_b, at); break;
-    case 1: hipLaunchKernelGGL((k_wavelet<T, 2>), g, b, 0, st, fb, a.cv_b, a.cv_a, w.cv_b, w.cv_a, a.var_b, a.var_a, w.var_b, w.var_a, at); break;
-    case 2: hipLaunchKernelGGL((k_wavelet<T, 4>), g, b, 0, st, fb, a.cv_a, a.cv_c, w.cv_a, w.cv_c, a.var_a, a.var_c, w.var_a, w.var_c, at); break;
-    case 3: hipLaunchKernelGGL((k_wavelet<T, 8>), g, b, 0, st, fb, a.cv_c, a.cv_a, w.cv_c, w.cv_a, a.var_c, a.var_a, w.var_c, w.var_a, at); break;
-    default: hipLaunchKernelGGL((k_wavelet<T, 16>), g, b, 0, st, fb, a.cv_a, a.cv_c, w.cv_a, w.cv_c, a.var_a, a.var_c, w.var_a, w.var_c, at); break;
+    case 0: hipLaunchKernelGGL((k_wavelet<T, 1>), g, b, 0, st, fb, a.cv_c, a.cv_b, w.cv_c, w.cv_b, a.var_c, a.var_b, w.var_c, w.var_b, at, (int)lat0, (int)hi); break;
+    case 1: hipLaunchKernelGGL((k_wavelet<T, 2>), g, b, 0, st, fb, a.cv_b, a.cv_a, w.cv_b, w.cv_a, a.var_b, a.var_a, w.var_b, w.var_a, at, (int)lat0, (int)hi); break;
+    case 2: hipLaunchKernelGGL((k_wavelet<T, 4>), g, b, 0, st, fb, a.cv_a, a.cv_c, w.cv_a, w.cv_c, a.var_a, a.var_c, w.var_a, w.var_c, at, (int)lat0, (int)hi); break;
+    case 3: hipLaunchKernelGGL((k_wavelet<T, 8>), g, b, 0, st, fb, a.cv_c, a.cv_a, w.cv_c, w.cv_a, a.var_c, a.var_a, w.var_c, w.var_a, at, (int)lat0, (int)hi); break;
+    default: hipLaunchKernelGGL((k_wavelet<T, 16>), g, b, 0, st, fb, a.cv_a, a.cv_c, w.cv_a, w.cv_c, a.var_a, a.var_c, w.var_a, w.var_c, at, (int)lat0, (int)hi); break;
     }
 }
 template <typename T>
@@ -666,7 +672,7 @@ void launch_read_u8(hipStream_t st, const uint8_t *src, float *dst, uint32_t n) 
     template void launch_depth_gradient<T>(hipStream_t, const FrameDev<T> &);                                          \
     template void launch_temporal_color<T>(hipStream_t, const FrameDev<T> &, float, float, bool);                      \
     template void launch_moments<T>(hipStream_t, const FrameDev<T> &, float);                                          \
-    template void launch_wavelet<T>(hipStream_t, const FrameDev<T> &, int, bool);                                      \
+    template void launch_wavelet<T>(hipStream_t, const FrameDev<T> &, int, bool, uint32_t, uint32_t);                                      \
     template void launch_finalize<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, const V4<T> *,             \
                                      const V4<T> *, V4<T> *, bool, bool, bool, float, float4 *, uint32_t, uint32_t);  \
     template void launch_copy_last_transform<T>(hipStream_t, const SceneDev<T> &, M4<T> *, uint32_t);                  \

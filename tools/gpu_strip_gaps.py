@@ -3,6 +3,7 @@ rocprofv3 --kernel-trace run whose summed kernel time per frame is compared with
 usage: gpu_strip_gaps.py [world] [frames]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
 import lprt_amd
 from lprt_amd import abi, scenes, dist as lp_dist
 
@@ -15,6 +16,8 @@ own_b, own_e = lp_dist.strip_rows(H, world, rank)
 win_b, win_e = lp_dist.window_rows(H, world, rank) if world > 1 else (0, H)
 with lprt_amd.Renderer(W, H, abi.F32, device=0, row_begin=win_b, row_end=win_e) as r:
     r.load_scene(sc)
+    out = torch.zeros((own_e - own_b, W, 4), dtype=torch.float32, device="cuda:0")  # as bench.py: the rank's rows of the gathered frame
+    r.set_output_target(out.data_ptr(), own_b, own_e - own_b)
     if world > 1:
         r.set_sample_rows(own_b, own_e - own_b)
     fs = abi.default_settings(spp=spp, gi_on=True, svgf=True)
