@@ -22,6 +22,10 @@
 #ifndef LPRT_ANYHIT_WAVES
 #define LPRT_ANYHIT_WAVES 4
 #endif
+#ifndef LPRT_ANYHIT_WAVES_F16
+#define LPRT_ANYHIT_WAVES_F16 5 // the half instantiation fits 96 registers with 4-10 spilled (single precision: 33-44)
+#endif
+template <typename T> struct AnyhitWaves { static constexpr int value = sizeof(T) == 2 ? LPRT_ANYHIT_WAVES_F16 : LPRT_ANYHIT_WAVES; };
 
 namespace lprt {
 
@@ -572,7 +576,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_spp_mean(FrameDev
     }
 }
 template <typename T, bool FIRST, bool COMPOSE, bool COUNT, bool WIDE>
-__global__ void __launch_bounds__(256, LPRT_ANYHIT_WAVES) k_trace_di(SceneDev<T> sc, FrameDev<T> fb0, ComposeArgs ca, Counters *counters) {
+__global__ void __launch_bounds__(256, AnyhitWaves<T>::value) k_trace_di(SceneDev<T> sc, FrameDev<T> fb0, ComposeArgs ca, Counters *counters) {
     const FrameDev<T> fb = at_sample(fb0, blockIdx.z);
     const uint32_t p = tile_pixel(fb);
     const uint32_t npix = fb.win.npix();
