@@ -375,13 +375,19 @@ int lprt_debug_sample_texture(lprt_ctx *ctx, uint32_t handle, const float *uv, u
 int lprt_debug_rng_states(lprt_ctx *ctx, uint64_t seed, uint32_t first, uint32_t count, uint32_t *out,
                           size_t out_words /* must be 6 * count */);
 
+/* Test hook: the single-precision transcendentals that shape rays (include/lprt_fmath.h) as the DEVICE evaluates them:
+ * op 0 logf, 1 sinf, 2 cosf, 3 tanf; out[i] = f(in[i]).  The parity tests compare them bit for bit with the host's
+ * evaluation of the same header. */
+int lprt_debug_fmath(lprt_ctx *ctx, int op, const float *in, uint32_t n, float *out);
+
 const char *lprt_version(void);
 
 /* ---- behaviour knobs --------------------------------------------------------------------- */
 
 /* Every A/B switch of the kernels is a per-context option.  The initial values come from the environment ONCE, in
  * lprt_create (variable named beside each option); nothing reads the environment after that, so a frame's behaviour cannot
- * change under the caller's feet.  Results never depend on these (the parity tests hold that); speed does. */
+ * change under the caller's feet.  Results never depend on these (the parity tests hold that); speed does -- with the one
+ * exception of LPRT_OPT_REFERENCE_SLAB, a parity instrument that says so below. */
 typedef enum {
     LPRT_OPT_WIDE_WALK = 0,        /* two BLAS levels per traversal step.  -1 (default): any-hit rays when some BLAS tree is
                                     * >= 6 levels deep; 0: never; 1: any-hit rays always.  lprt_trace_rays follows the same
@@ -427,7 +433,16 @@ typedef enum {
                                      * that start next to each other meet in one XCD's L2 -- and steal from the other ranges when
                                      * theirs is empty.  0: one counter, batches go to whichever wave asks next.  Results never
                                      * depend on it.  LPRT_STREAM_XCD */
-    LPRT_OPT_COUNT = 15
+    LPRT_OPT_REFERENCE_SLAB = 15,   /* 0 (default): the slab parameters of half boxes are evaluated in f32 (difference in half, product
+                                     * with the f32 reciprocal, min/max and slack in f32): nothing overflows, and the GPU never culls a
+                                     * box the ray reaches.  1: ray_aabb_intersection_scene / _object evaluated in float16 operation for
+                                     * operation as rt/rtrt/cuda.hpp:70-149 (half subtraction, half DIVISION, half slack products; a
+                                     * parameter beyond 65504 drops its axis) -- the reference's own lossy test, several times slower,
+                                     * for parity work: it separates "the GPU culls less than the reference" from "the two trees
+                                     * differ".  Unlike every other option this one CHANGES half-precision results (which boxes a ray
+                                     * is admitted to); single precision is unaffected (its default arithmetic is the reference's).
+                                     * LPRT_REFERENCE_SLAB */
+    LPRT_OPT_COUNT = 16
 } lprt_option;
 int lprt_set_option(lprt_ctx *ctx, lprt_option option, int value);
 int lprt_get_option(lprt_ctx *ctx, lprt_option option, int *value);

@@ -96,7 +96,7 @@ STAGE_KERNELS = {"primary": "k_fill_gbuffer", "temporal_map": "k_temporal_map", 
 # lprt_option, in enum order
 OPTIONS = ["wide_walk", "tlas_mode", "axis_reject", "svgf_always_test", "blas_builder", "blas_local", "debug_sync", "ray_stream",
            "stream_wide_closest", "stream_refill_min", "stream_node_min", "stream_sched", "sample_batch",
-           "floor_reprojection", "stream_xcd"]
+           "floor_reprojection", "stream_xcd", "reference_slab"]
 RNG_STATE_WORDS = 6
 
 

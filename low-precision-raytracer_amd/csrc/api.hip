@@ -13,6 +13,17 @@
 #include <string>
 #include <vector>
 
+// A ray-casting launcher in the variant the context asks for (kernels.hpp): the reference-arithmetic half slab tests exist
+// for DataT = half only (in single precision the default arithmetic IS the reference's).  Used inside Ctx<T> members.
+#define LPRT_TRACE(fn)                                                                                                                \
+    (this->reference_slab() ? [] {                                                                                                    \
+        if constexpr (sizeof(T) == 2)                                                                                                 \
+            return &::lprt::refslab::fn<T>;                                                                                           \
+        else                                                                                                                          \
+            return &::lprt::fastslab::fn<T>;                                                                                          \
+    }()                                                                                                                               \
+                            : &::lprt::fastslab::fn<T>)
+
 namespace lprt {
 
 // RDTexture owners (memory.hpp:334-369): RGBA8 texel arrays + the descriptor table the kernels index by handle
@@ -80,7 +91,8 @@ struct CtxBase {
     uint32_t sample_first = 0, sample_rows = 0; // 0 rows: the whole window
     int next_phase = LPRT_PHASE_SAMPLE;
     // behaviour knobs (lprt_option): initialised from the environment once, in lprt_create; never read from it afterwards
-    int opts[LPRT_OPT_COUNT] = {-1, -1, 1, 0, 0, 1, 0, -1, 0, 12, 20, 0, (int)LPRT_MAX_SAMPLE_BATCH, 0, 1};
+    int opts[LPRT_OPT_COUNT] = {-1, -1, 1, 0, 0, 1, 0, -1, 0, 12, 20, 0, (int)LPRT_MAX_SAMPLE_BATCH, 0, 1, 0};
+    bool reference_slab() const { return opts[LPRT_OPT_REFERENCE_SLAB] != 0; }
     void options_from_environment() {
         if (const char *w = std::getenv("LPRT_WIDE_WALK"))
             opts[LPRT_OPT_WIDE_WALK] = w[0] == '1' ? 1 : 0;
@@ -106,6 +118,8 @@ struct CtxBase {
             opts[LPRT_OPT_STREAM_XCD] = r[0] == '0' ? 0 : 1;
         if (const char *r = std::getenv("LPRT_STREAM_SCHED"))
             opts[LPRT_OPT_STREAM_SCHED] = r[0] == '1' ? 1 : 0;
+        if (const char *r = std::getenv("LPRT_REFERENCE_SLAB"))
+            opts[LPRT_OPT_REFERENCE_SLAB] = r[0] == '1' ? 1 : 0;
         if (const char *r = std::getenv("LPRT_STREAM_WIDE_CLOSEST"))
             opts[LPRT_OPT_STREAM_WIDE_CLOSEST] = r[0] == '1' ? 1 : 0;
     }
@@ -443,7 +457,7 @@ template <typename T> struct Impl : CtxBase {
                 return fs.seeds[3 * s + (uint32_t)which];
             return 3 * (frame_index * spp + s) + 1 + (uint64_t)which;
         };
-        stage(LPRT_STAGE_PRIMARY, [&] { launch_fill_gbuffer<T>(stream, sc, fb, stage_counters(LPRT_STAGE_PRIMARY)); });
+        stage(LPRT_STAGE_PRIMARY, [&] { LPRT_TRACE(launch_fill_gbuffer)(stream, sc, fb, stage_counters(LPRT_STAGE_PRIMARY)); });
         const bool first = frame_index == 0;
         const bool wide_walk = wide_anyhit(), streams = ray_streams(), wide_closest = opts[LPRT_OPT_STREAM_WIDE_CLOSEST] != 0;
         // round-0 shadow rays start on the camera-visible surface and aim at the same few lights: coherent, and the fused
@@ -497,10 +511,10 @@ template <typename T> struct Impl : CtxBase {
             if (n_round0)
                 stage(LPRT_STAGE_TRACE_DI1, [&] {
                     if (stream_round0) {
-                        launch_stream_di<T>(stream, sc, sv, true, n_round0, next_stream_counter(), stage_counters(LPRT_STAGE_TRACE_DI1), wide_walk);
+                        LPRT_TRACE(launch_stream_di)(stream, sc, sv, true, n_round0, next_stream_counter(), stage_counters(LPRT_STAGE_TRACE_DI1), wide_walk);
                         launch_accum_di<T>(stream, sv, true, fs.gi_on != 0, fs.add_direct_out != 0, n_round0, reuse);
                     } else
-                        launch_trace_di<T>(stream, sc, sv, true, fs.gi_on != 0, fs.add_direct_out != 0, n_round0, reuse,
+                        LPRT_TRACE(launch_trace_di)(stream, sc, sv, true, fs.gi_on != 0, fs.add_direct_out != 0, n_round0, reuse,
                                            stage_counters(LPRT_STAGE_TRACE_DI1), wide_walk);
                 });
             if (fs.gi_on) {
@@ -508,17 +522,17 @@ template <typename T> struct Impl : CtxBase {
                 // (ray streams: each of the two as a traversal kernel + a per-pixel kernel, timed as stages of their own)
                 if (streams) {
                     stage(LPRT_STAGE_TRACE_GI, [&] {
-                        launch_stream_gi<T>(stream, sc, sv, n, next_stream_counter(), stage_counters(LPRT_STAGE_TRACE_GI), wide_closest);
+                        LPRT_TRACE(launch_stream_gi)(stream, sc, sv, n, next_stream_counter(), stage_counters(LPRT_STAGE_TRACE_GI), wide_closest);
                     });
                     stage(LPRT_STAGE_SHADE2, [&] { launch_shade2<T>(stream, sc, sv, n); });
                     stage(LPRT_STAGE_TRACE_DI2, [&] {
-                        launch_stream_di<T>(stream, sc, sv, false, n, next_stream_counter(), stage_counters(LPRT_STAGE_TRACE_DI2), wide_walk);
+                        LPRT_TRACE(launch_stream_di)(stream, sc, sv, false, n, next_stream_counter(), stage_counters(LPRT_STAGE_TRACE_DI2), wide_walk);
                     });
                     stage(LPRT_STAGE_COMPOSE, [&] { launch_accum_di<T>(stream, sv, false, true, fs.add_direct_out != 0, n, reuse); });
                 } else {
-                    stage(LPRT_STAGE_TRACE_GI, [&] { launch_trace_gi<T>(stream, sc, sv, n, stage_counters(LPRT_STAGE_TRACE_GI)); });
+                    stage(LPRT_STAGE_TRACE_GI, [&] { LPRT_TRACE(launch_trace_gi)(stream, sc, sv, n, stage_counters(LPRT_STAGE_TRACE_GI)); });
                     stage(LPRT_STAGE_TRACE_DI2, [&] {
-                        launch_trace_di<T>(stream, sc, sv, false, true, fs.add_direct_out != 0, n, reuse, stage_counters(LPRT_STAGE_TRACE_DI2), wide_walk);
+                        LPRT_TRACE(launch_trace_di)(stream, sc, sv, false, true, fs.add_direct_out != 0, n, reuse, stage_counters(LPRT_STAGE_TRACE_DI2), wide_walk);
                     });
                 }
             }
@@ -799,11 +813,11 @@ template <typename T> struct Impl : CtxBase {
         if (ray_streams()) { // the persistent traversal the frame kernels take in large scenes
             d_stream_counters.reserve(sizeof(uint32_t) * LPRT_STREAM_COUNTER_WORDS);
             LPRT_HIP(hipMemsetAsync(d_stream_counters.ptr, 0, sizeof(uint32_t) * LPRT_STREAM_COUNTER_WORDS, stream));
-            launch_stream_rays<T>(stream, scene_dev(), d_rays.as<lprt_ray>(), n, find_any != 0,
+            LPRT_TRACE(launch_stream_rays)(stream, scene_dev(), d_rays.as<lprt_ray>(), n, find_any != 0,
                                   find_any ? wide : (wide || opts[LPRT_OPT_STREAM_WIDE_CLOSEST] != 0), d_hits.as<lprt_hit>(),
                                   d_stream_counters.as<uint32_t>(), stage_counters(LPRT_STAGE_PRIMARY));
         } else {
-            launch_trace_rays<T>(stream, scene_dev(), d_rays.as<lprt_ray>(), n, find_any != 0, wide, d_hits.as<lprt_hit>(),
+            LPRT_TRACE(launch_trace_rays)(stream, scene_dev(), d_rays.as<lprt_ray>(), n, find_any != 0, wide, d_hits.as<lprt_hit>(),
                                  stage_counters(LPRT_STAGE_PRIMARY));
         }
         LPRT_HIP(hipGetLastError());
@@ -1159,6 +1173,24 @@ int lprt_debug_sample_texture(lprt_ctx *ctx, uint32_t handle, const float *uv, u
         launch_sample_texture(c.stream, c.tex.table.as<Texture>(), c.tex.lut.as<float>(), handle, d_uv.as<float>(), n, d_out.as<float>());
         LPRT_HIP(hipGetLastError());
         LPRT_HIP(hipMemcpyAsync(rgba, d_out.ptr, sizeof(float) * 4 * (size_t)n, hipMemcpyDeviceToHost, c.stream));
+        LPRT_HIP(hipStreamSynchronize(c.stream));
+    });
+}
+int lprt_debug_fmath(lprt_ctx *ctx, int op, const float *in, uint32_t n, float *out) {
+    return guarded(ctx, [&](CtxBase &c) {
+        if (op < 0 || op > 3)
+            throw std::string("unknown fmath op");
+        if (n && (!in || !out))
+            throw std::string("null in/out pointer");
+        if (!n)
+            return;
+        DevBuf d_in, d_out;
+        d_in.reserve(sizeof(float) * (size_t)n);
+        d_out.reserve(sizeof(float) * (size_t)n);
+        LPRT_HIP(hipMemcpyAsync(d_in.ptr, in, sizeof(float) * (size_t)n, hipMemcpyHostToDevice, c.stream));
+        launch_fmath(c.stream, op, d_in.as<float>(), n, d_out.as<float>());
+        LPRT_HIP(hipGetLastError());
+        LPRT_HIP(hipMemcpyAsync(out, d_out.ptr, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost, c.stream));
         LPRT_HIP(hipStreamSynchronize(c.stream));
     });
 }

@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/lprt_fmath.h"
 
 namespace lprt {
 
@@ -65,7 +66,8 @@ template <typename T> LPRT_DEV T tpow5(T a) {
     const float f = (float)a, f2 = f * f;
     return cvt<T>((f2 * f2) * f);
 }
-template <typename T> LPRT_DEV T ttan(T a) { return cvt<T>(::tanf((float)a)); }
+// tan(fovy / 2) shapes every primary ray: include/lprt_fmath.h's form, shared with the CPU restatement
+template <typename T> LPRT_DEV T ttan(T a) { return cvt<T>(lprt_tanf((float)a)); }
 // reciprocal used by Matrix::operator/=(x): DataT(1.0 / double(x)) == correctly rounded 1/x
 template <typename T> LPRT_DEV T trcp(T a) { return cvt<T>(1.0f / (float)a); }
 // (int) of a float as the hardware converts it (NaN -> 0, saturating), cuda.hpp:2302

@@ -4,10 +4,43 @@
 
 namespace lprt {
 
+// Every kernel that casts rays exists in two variants, compiled from the same sources into two namespaces:
+//   fastslab  the product's default: slab parameters of half boxes in f32 (trace.hpp);
+//   refslab   half instantiation only (LPRT_OPT_REFERENCE_SLAB): ray_aabb_intersection_* evaluated in float16 operation for
+//             operation as rt/rtrt/cuda.hpp:70-149 does -- half subtraction, half division, half slack -- so that the fp16
+//             parity tests can tell "the GPU culls less than the reference's lossy half test" from "the trees differ".
+// The second variant is a translation unit of its own (pipeline_refslab.hip, trace_kernels_refslab.hip define
+// LPRT_REFSLAB_TU and include the source), so the default kernels' code and register allocation do not change by a bit.
+#ifdef LPRT_REFSLAB_TU
+#define LPRT_SLAB_NS refslab
+#else
+#define LPRT_SLAB_NS fastslab
+#endif
+#define LPRT_VAR_BEGIN namespace LPRT_SLAB_NS {
+#define LPRT_VAR_END }
+#define LPRT_TRACE_LAUNCHERS                                                                                                                          \
+    /* trace_kernels.hip; wide: the two-levels-per-step BLAS walk (trace.hpp) */                                                                     \
+    template <typename T>                                                                                                                             \
+    void launch_trace_rays(hipStream_t st, const SceneDev<T> &sc, const lprt_ray *rays, uint32_t n, bool any, bool wide, lprt_hit *hits,              \
+                           Counters *counters);                                                                                                       \
+    /* pipeline.hip */                                                                                                                                \
+    template <typename T> void launch_fill_gbuffer(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, Counters *c);                       \
+    /* the last round of a sample also runs write_clean_color; wide: deep BLAS trees, two levels per step */                                         \
+    template <typename T>                                                                                                                             \
+    void launch_trace_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, bool gi_on, bool add_direct, uint32_t slots,      \
+                         bool reuse, Counters *c, bool wide);                                                                                         \
+    template <typename T> void launch_trace_gi(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t slots, Counters *c);           \
+    /* ray streams (stream.hpp): persistent waves that refill finished lanes.  `counter` is a zeroed device word owned by the launch. */           \
+    template <typename T>                                                                                                                             \
+    void launch_stream_gi(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t slots, uint32_t *counter, Counters *c, bool wide);  \
+    template <typename T>                                                                                                                             \
+    void launch_stream_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, uint32_t slots, uint32_t *counter, Counters *c,  \
+                          bool wide);                                                                                                                 \
+    template <typename T>                                                                                                                             \
+    void launch_stream_rays(hipStream_t st, const SceneDev<T> &sc, const lprt_ray *rays, uint32_t n, bool any, bool wide, lprt_hit *hits,            \
+                            uint32_t *counter, Counters *counters);
+
 // trace_kernels.hip
-template <typename T>
-void launch_trace_rays(hipStream_t st, const SceneDev<T> &sc, const lprt_ray *rays, uint32_t n, bool any, bool wide, lprt_hit *hits,
-                       Counters *counters); // wide: the two-levels-per-step BLAS walk (trace.hpp)
 template <typename T>
 void launch_make_objrecs(hipStream_t st, const ObjSlot<T> *slots, const ObjConst<T> *objects, const BlasInfo *blas, const T *roots, uint32_t n,
                          uint32_t n_vaos, ObjRec<T> *out);
@@ -21,6 +54,7 @@ struct CopyJobs {
     uint32_t n;
 };
 void launch_copy_jobs(hipStream_t st, const CopyJobs &jobs, size_t longest);
+void launch_fmath(hipStream_t st, int op, const float *in, uint32_t n, float *out); // lprt_debug_fmath
 void launch_sample_texture(hipStream_t st, const Texture *textures, const float *lut, uint32_t handle, const float *uv, uint32_t n, float *rgba);
 
 
@@ -32,28 +66,21 @@ struct SampleBatch {
     uint32_t rng_d[LPRT_MAX_SAMPLE_BATCH];    // d word of each slot's shade seed
     uint32_t reuse_direct;                    // lprt_frame_settings.reuse_direct_light: round 0 runs for sample 0 only
 };
-template <typename T> void launch_fill_gbuffer(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, Counters *c);
+namespace fastslab {
+LPRT_TRACE_LAUNCHERS
+}
+namespace refslab { // only the h16 instantiations exist
+LPRT_TRACE_LAUNCHERS
+}
 template <typename T> void launch_temporal_map(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, uint32_t rng_d, bool floor_taps);
 template <typename T> void launch_shade(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool no_gi, const SampleBatch &sb); // round 0; round 1 runs inside k_trace_gi / as k_shade2
-template <typename T>
-void launch_trace_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, bool gi_on, bool add_direct, uint32_t slots, bool reuse,
-                     Counters *c, bool wide); // the last round of a sample also runs write_clean_color; wide: deep BLAS trees, two levels per step
-template <typename T> void launch_trace_gi(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t slots, Counters *c);
 template <typename T> void launch_spp_mean(hipStream_t st, const FrameDev<T> &fb, uint32_t first, uint32_t count, uint32_t spp); // after a batch's last stage
 
-// ray streams (stream.hpp; kernels in pipeline.hip): persistent waves that refill finished lanes.  `counter` is a zeroed
-// device word owned by this launch.  launch_stream_gi leaves a hit record per pixel for launch_shade2 (shade #2 of the
-// hits); launch_stream_di leaves a visibility byte per pixel and light slot for launch_accum_di (accumulate_di_light, and
-// in the last round of a sample write_clean_color) -- together what the fused per-pixel kernels do.
-template <typename T>
-void launch_stream_gi(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t slots, uint32_t *counter, Counters *c, bool wide);
+// launch_stream_gi leaves a hit record per pixel for launch_shade2 (shade #2 of the hits); launch_stream_di leaves a
+// visibility byte per pixel and light slot for launch_accum_di (accumulate_di_light, and in the last round of a sample
+// write_clean_color) -- together what the fused per-pixel kernels do.
 template <typename T> void launch_shade2(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t slots);
-template <typename T>
-void launch_stream_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, uint32_t slots, uint32_t *counter, Counters *c, bool wide);
 template <typename T> void launch_accum_di(hipStream_t st, const FrameDev<T> &fb, bool first, bool gi_on, bool add_direct, uint32_t slots, bool reuse);
-template <typename T>
-void launch_stream_rays(hipStream_t st, const SceneDev<T> &sc, const lprt_ray *rays, uint32_t n, bool any, bool wide, lprt_hit *hits, uint32_t *counter,
-                        Counters *counters);
 
 // svgf.hip
 template <typename T> void launch_depth_gradient(hipStream_t st, const FrameDev<T> &fb);

@@ -12,6 +12,9 @@
 #include "trace.hpp"
 #include "stream.hpp"
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <utility>
 
 // Waves per SIMD the traversal kernels are compiled for (VGPR budget = 512 / waves).  Traversal is latency-bound, so
 // the closest-hit kernels take a fifth wave at the price of a few spilled registers (measured on MI355X, Cornell 1080p:
@@ -123,6 +126,7 @@ template <typename T> LPRT_DEV HitAttr<T> interpolate_hit(const SceneDev<T> &sc,
 }
 
 // ---- G2: fill_gbuffer_in_cuda (cuda.hpp:950-1012) ---------------------------------------------------------
+LPRT_VAR_BEGIN
 template <typename T, bool COUNT>
 __global__ void __launch_bounds__(256, ClosestWaves<T>::value) k_fill_gbuffer(SceneDev<T> sc, FrameDev<T> fb, Counters *counters) {
     const uint32_t p = tile_pixel(fb);
@@ -161,10 +165,12 @@ __global__ void __launch_bounds__(256, ClosestWaves<T>::value) k_fill_gbuffer(Sc
     }
     flush_counters<COUNT>(cnt, counters);
 }
+LPRT_VAR_END
 
 // ---- V1: generate_temporal_map_step1/2 (cuda.hpp:2265-2416) ------------------------------------------------
 // `first` = no history yet (DEVIATION Q7: frame_count = 0 everywhere).  The neighbours' previous frame counts
 // come from a snapshot plane (prev_frame_count), which replaces the reference's racy two-step scheme.
+#ifndef LPRT_REFSLAB_TU
 template <typename T>
 __global__ void __launch_bounds__(256) k_temporal_map(SceneDev<T> sc, FrameDev<T> fb, int first, uint32_t rng_d, int floor_taps) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -272,6 +278,7 @@ __global__ void __launch_bounds__(256) k_temporal_map(SceneDev<T> sc, FrameDev<T
 // ---- S: shade<T,4,FIRST_ROUND,NO_GI> (cuda.hpp:1751-2056) ----------------------------------------------------
 // The surface point shade() works on: a G-buffer texel (round 0, loaded by k_shade) or the interpolated GI hit
 // (round 1, handed over in registers by k_trace_gi: the PixelShaderInput record never goes through memory).
+#endif // LPRT_REFSLAB_TU
 template <typename T> struct ShadeIn {
     V3<T> position, raw_normal, raw_tangent, vertex_color;
     V4<T> uv4;
@@ -472,6 +479,7 @@ LPRT_DEV void shade_and_store(const SceneDev<T> &sc, const FrameDev<T> &fb, uint
     }
 }
 
+#ifndef LPRT_REFSLAB_TU
 template <typename T, bool NO_GI>
 __global__ void __launch_bounds__(256) k_shade(SceneDev<T> sc, FrameDev<T> fb0, SampleBatch sa) {
     const FrameDev<T> fb = at_sample(fb0, blockIdx.z);
@@ -505,10 +513,12 @@ __global__ void __launch_bounds__(256) k_shade(SceneDev<T> sc, FrameDev<T> fb0, 
     }
     shade_and_store<T, true, NO_GI>(sc, fb, p, rng_d, in, sample == 0u, skip_direct != 0u);
 }
+#endif // LPRT_REFSLAB_TU
 
 // ---- TD + A (+ W): trace_di_light + accumulate_di_light (cuda.hpp:2058-2081, 2143-2159); the LAST round of a sample
 // also runs write_clean_color (cuda.hpp:2170-2199) and the build-side spp mean on the radiance it just completed:
 // sample s of n accumulates in f32 in sample order; the last sample divides once and rounds once to DataT.
+
 struct ComposeArgs {
     int gi_on, add_direct_out;
     uint32_t reuse_direct; // round 0 ran for sample 0 only (lprt_frame_settings.reuse_direct_light): its radiance is slot 0's
@@ -536,6 +546,7 @@ LPRT_DEV void compose_tail(const FrameDev<T> &fb, const FrameDev<T> &slot0, cons
 }
 // The build-side spp mean: sample s of n accumulates in f32 in sample order; the last sample divides once and rounds once to
 // DataT (spp = 1 is exactly a reference frame).  One launch per batch of samples, after the batch's last stage.
+#ifndef LPRT_REFSLAB_TU
 template <typename T> __global__ void __launch_bounds__(256) k_spp_mean(FrameDev<T> fb, uint32_t first, uint32_t count, uint32_t spp) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= fb.win.npix())
@@ -579,6 +590,8 @@ template <typename T> __global__ void __launch_bounds__(256) k_spp_mean(FrameDev
         fb.raw_gi_white[p] = w;
     }
 }
+#endif // LPRT_REFSLAB_TU
+LPRT_VAR_BEGIN
 template <typename T, bool FIRST, bool COMPOSE, bool COUNT, bool WIDE>
 __global__ void __launch_bounds__(256, AnyhitWaves<T>::value) k_trace_di(SceneDev<T> sc, FrameDev<T> fb0, ComposeArgs ca, Counters *counters) {
     const FrameDev<T> fb = at_sample(fb0, blockIdx.z);
@@ -615,6 +628,7 @@ __global__ void __launch_bounds__(256, AnyhitWaves<T>::value) k_trace_di(SceneDe
     }
     flush_counters<COUNT>(cnt, counters);
 }
+LPRT_VAR_END
 
 // ---- TG + S2: trace_gi (cuda.hpp:2083-2141) followed, in the same thread, by shade #2 of the hit ---------------------
 // The reference stores a PixelShaderInput record per pixel and launches shade<false,true> over it; nothing but the
@@ -648,6 +662,7 @@ template <typename T> LPRT_DEV void shade_gi_hit(const SceneDev<T> &sc, const Fr
     shade_and_store<T, false, true>(sc, fb, p, 0u, in, false);
 }
 
+LPRT_VAR_BEGIN
 template <typename T, bool COUNT>
 __global__ void __launch_bounds__(256, ClosestWaves<T>::value) k_trace_gi(SceneDev<T> sc, FrameDev<T> fb0, Counters *counters) {
     const FrameDev<T> fb = at_sample(fb0, blockIdx.z);
@@ -674,6 +689,7 @@ __global__ void __launch_bounds__(256, ClosestWaves<T>::value) k_trace_gi(SceneD
     }
     flush_counters<COUNT>(cnt, counters);
 }
+LPRT_VAR_END
 
 static inline dim3 grid_for(uint32_t n) { return dim3((n + 255) / 256); }
 
@@ -787,6 +803,7 @@ template <typename T> struct HostRaySource { // lprt_trace_rays
     }
 };
 
+LPRT_VAR_BEGIN
 template <typename T, bool COUNT, bool WIDE>
 __global__ void __launch_bounds__(256, LPRT_STREAM_WAVES) k_stream_gi(SceneDev<T> sc, FrameDev<T> fb, uint32_t slots, uint32_t n_items, uint32_t *counter,
                                                                        Counters *counters) {
@@ -811,7 +828,9 @@ __global__ void __launch_bounds__(256, LPRT_STREAM_WAVES) k_stream_rays(SceneDev
     trace_stream<T, ANY, COUNT, WIDE>(sc, src, n, counter, cnt);
     flush_counters<COUNT>(cnt, counters);
 }
+LPRT_VAR_END
 
+#ifndef LPRT_REFSLAB_TU
 // shade #2 of every pixel on the hit record its GI ray left (the tail of k_trace_gi as a kernel of its own)
 template <typename T> __global__ void __launch_bounds__(256) k_shade2(SceneDev<T> sc, FrameDev<T> fb0) {
     const FrameDev<T> fb = at_sample(fb0, blockIdx.z);
@@ -857,37 +876,53 @@ __global__ void __launch_bounds__(256) k_accum_di(FrameDev<T> fb0, ComposeArgs c
     if (COMPOSE)
         compose_tail<T, FIRST>(fb, fb0, ca, p, cur);
 }
+#endif // LPRT_REFSLAB_TU
 
 // persistent grid: as many workgroups as the chip holds at once (occupancy x CUs), never more than the stream has work for
+// (the occupancy query is cached per (device, kernel): instantiations that differ only in their template arguments share a
+// function-pointer TYPE, so the cache cannot be a static of this template alone)
 template <typename K> static dim3 stream_grid(K kernel, uint32_t n_items) {
-    static int per_cu = 0, cus = 0; // one value per kernel instantiation (K is a distinct function per template argument set)
-    if (!per_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        (void)hipGetDevice(&dev);
-        (void)hipGetDeviceProperties(&prop, dev);
-        cus = prop.multiProcessorCount;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu <= 0)
-            per_cu = LPRT_STREAM_WAVES;
+    static std::mutex mu;
+    static std::map<std::pair<int, const void *>, uint32_t> resident; // workgroups the device holds at once
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    uint32_t have = 0;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        const auto key = std::make_pair(dev, reinterpret_cast<const void *>(kernel));
+        auto it = resident.find(key);
+        if (it == resident.end()) {
+            int per_cu = 0, cus = 0;
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu <= 0)
+                per_cu = LPRT_STREAM_WAVES;
+            it = resident.emplace(key, (uint32_t)(per_cu * std::max(cus, 1))).first;
+        }
+        have = it->second;
     }
-    const uint32_t want = (n_items + 255u) / 256u, have = (uint32_t)(per_cu * cus);
+    const uint32_t want = (n_items + 255u) / 256u;
     return dim3(std::max(1u, std::min(want, have)));
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------
 
+LPRT_VAR_BEGIN
 template <typename T> void launch_fill_gbuffer(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, Counters *c) {
     if (c)
         hipLaunchKernelGGL((k_fill_gbuffer<T, true>), tile_grid(fb), dim3(256), 0, st, sc, fb, c);
     else
         hipLaunchKernelGGL((k_fill_gbuffer<T, false>), tile_grid(fb), dim3(256), 0, st, sc, fb, c);
 }
+LPRT_VAR_END
+#ifndef LPRT_REFSLAB_TU
 template <typename T> void launch_temporal_map(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, uint32_t rng_d, bool floor_taps) {
     hipLaunchKernelGGL(k_temporal_map<T>, grid_for(fb.win.npix()), dim3(256), 0, st, sc, fb, first ? 1 : 0, rng_d, floor_taps ? 1 : 0);
 }
+#endif // LPRT_REFSLAB_TU
 // tiles x sample slots of the batch
 template <typename T> static inline dim3 tile_grid_z(const FrameDev<T> &fb, uint32_t slots) { return dim3(tile_grid(fb).x, 1, slots); }
 
+#ifndef LPRT_REFSLAB_TU
 template <typename T> void launch_shade(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool no_gi, const SampleBatch &sb) {
     const dim3 g = tile_grid_z(fb, sb.count), b(256);
     if (!no_gi)
@@ -895,6 +930,8 @@ template <typename T> void launch_shade(hipStream_t st, const SceneDev<T> &sc, c
     else
         hipLaunchKernelGGL((k_shade<T, true>), g, b, 0, st, sc, fb, sb);
 }
+#endif // LPRT_REFSLAB_TU
+LPRT_VAR_BEGIN
 // wide: the BLAS set holds deep trees (GeometryStore::max_depth >= 6): the shadow rays walk them two levels per step
 template <typename T, bool WIDE>
 static void launch_trace_di_w(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, bool gi_on, bool add_direct, uint32_t slots,
@@ -932,10 +969,14 @@ template <typename T> void launch_trace_gi(hipStream_t st, const SceneDev<T> &sc
     else
         hipLaunchKernelGGL((k_trace_gi<T, false>), tile_grid_z(fb, slots), dim3(256), 0, st, sc, fb, c);
 }
+LPRT_VAR_END
+#ifndef LPRT_REFSLAB_TU
 template <typename T> void launch_spp_mean(hipStream_t st, const FrameDev<T> &fb, uint32_t first, uint32_t count, uint32_t spp) {
     hipLaunchKernelGGL(k_spp_mean<T>, grid_for(fb.win.npix()), dim3(256), 0, st, fb, first, count, spp);
 }
+#endif // LPRT_REFSLAB_TU
 
+LPRT_VAR_BEGIN
 template <typename T, bool WIDE>
 static void launch_stream_gi_w(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t slots, uint32_t *counter, Counters *c) {
     const uint32_t per_slot = n_blocks8(fb) * 64u, n_items = per_slot * slots;
@@ -944,9 +985,13 @@ static void launch_stream_gi_w(hipStream_t st, const SceneDev<T> &sc, const Fram
     else
         hipLaunchKernelGGL((k_stream_gi<T, false, WIDE>), stream_grid(k_stream_gi<T, false, WIDE>, n_items), dim3(256), 0, st, sc, fb, slots, n_items, counter, c);
 }
+LPRT_VAR_END
+#ifndef LPRT_REFSLAB_TU
 template <typename T> void launch_shade2(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t slots) {
     hipLaunchKernelGGL(k_shade2<T>, tile_grid_z(fb, slots), dim3(256), 0, st, sc, fb);
 }
+#endif // LPRT_REFSLAB_TU
+LPRT_VAR_BEGIN
 template <typename T>
 void launch_stream_gi(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t slots, uint32_t *counter, Counters *c, bool wide) {
     if (wide)
@@ -981,6 +1026,8 @@ void launch_stream_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &
             launch_stream_di_w<T, false, false>(st, sc, fb, slots, counter, c);
     }
 }
+LPRT_VAR_END
+#ifndef LPRT_REFSLAB_TU
 template <typename T>
 void launch_accum_di(hipStream_t st, const FrameDev<T> &fb, bool first, bool gi_on, bool add_direct, uint32_t slots, bool reuse) {
     const dim3 g = tile_grid_z(fb, slots), b(256);
@@ -992,6 +1039,8 @@ void launch_accum_di(hipStream_t st, const FrameDev<T> &fb, bool first, bool gi_
     else
         hipLaunchKernelGGL((k_accum_di<T, false, true>), g, b, 0, st, fb, ca);
 }
+#endif // LPRT_REFSLAB_TU
+LPRT_VAR_BEGIN
 template <typename T, bool ANY, bool WIDE>
 static void launch_stream_rays_w(hipStream_t st, const SceneDev<T> &sc, const lprt_ray *rays, uint32_t n, lprt_hit *hits, uint32_t *counter, Counters *c) {
     if (c)
@@ -1014,20 +1063,30 @@ void launch_stream_rays(hipStream_t st, const SceneDev<T> &sc, const lprt_ray *r
         launch_stream_rays_w<T, false, false>(st, sc, rays, n, hits, counter, counters);
 }
 
-#define INST(T)                                                                                                        \
+#define INST_TRACE(T)                                                                                                  \
     template void launch_stream_gi<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, uint32_t, uint32_t *, Counters *, bool); \
-    template void launch_shade2<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, uint32_t);                   \
     template void launch_stream_di<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, uint32_t, uint32_t *, Counters *, bool); \
-    template void launch_accum_di<T>(hipStream_t, const FrameDev<T> &, bool, bool, bool, uint32_t, bool);              \
-    template void launch_spp_mean<T>(hipStream_t, const FrameDev<T> &, uint32_t, uint32_t, uint32_t);                  \
     template void launch_stream_rays<T>(hipStream_t, const SceneDev<T> &, const lprt_ray *, uint32_t, bool, bool, lprt_hit *, uint32_t *, Counters *); \
     template void launch_fill_gbuffer<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, Counters *);          \
-    template void launch_temporal_map<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, uint32_t, bool);      \
-    template void launch_shade<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, const SampleBatch &);   \
     template void launch_trace_di<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, bool, bool, uint32_t, bool, Counters *, bool); \
     template void launch_trace_gi<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, uint32_t, Counters *);
+#ifndef LPRT_REFSLAB_TU
+INST_TRACE(float)
+#endif
+INST_TRACE(h16)
+#undef INST_TRACE
+LPRT_VAR_END
+
+#ifndef LPRT_REFSLAB_TU
+#define INST(T)                                                                                                        \
+    template void launch_shade2<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, uint32_t);                   \
+    template void launch_accum_di<T>(hipStream_t, const FrameDev<T> &, bool, bool, bool, uint32_t, bool);              \
+    template void launch_spp_mean<T>(hipStream_t, const FrameDev<T> &, uint32_t, uint32_t, uint32_t);                  \
+    template void launch_temporal_map<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, uint32_t, bool);      \
+    template void launch_shade<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, const SampleBatch &);
 INST(float)
 INST(h16)
 #undef INST
+#endif // LPRT_REFSLAB_TU
 
 } // namespace lprt

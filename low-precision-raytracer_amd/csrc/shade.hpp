@@ -2,6 +2,7 @@
 // Restates rt/rtrt/bsdf.hpp:12-139 and rt/rtrt/cuda.hpp:1713-1749 with explicit rounding points.
 #pragma once
 #include "types.hpp"
+#include "../../include/lprt_fmath.h"
 
 namespace lprt {
 
@@ -34,10 +35,13 @@ LPRT_DEV float xorwow_normal(Xorwow &s) { // curand_normal: Box-Muller pair, sec
     uint32_t x = xorwow_next(s), y = xorwow_next(s);
     float u = (float)x * 2.3283064e-10f + (2.3283064e-10f / 2.0f);
     float v = (float)y * 1.46291807e-09f + (1.46291807e-09f / 2.0f);
-    float r = __builtin_sqrtf(-2.0f * ::logf(u));
-    s.bm_extra = r * ::cosf(v);
+    // logf / sinf / cosf decide GI ray directions: the shared single-precision forms of include/lprt_fmath.h, so that the
+    // CPU restatement casts the bit-identical ray (libdevice vs libm differed in the last bit for ~0.3 % of the directions)
+    float r = __builtin_sqrtf(-2.0f * lprt_logf(u)), sn, cs;
+    lprt_sincosf(v, &sn, &cs);
+    s.bm_extra = r * cs;
     s.bm_flag = 1;
-    return r * ::sinf(v);
+    return r * sn;
 }
 
 // ---- BRDF (bsdf.hpp) -----------------------------------------------------------------------------------

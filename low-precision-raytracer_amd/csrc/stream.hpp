@@ -219,6 +219,9 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items, ui
             RayT<T> wray{world.o, world.d};
             RaySlab<T> wrs{};
             wrs.o = wray.o;
+#ifdef LPRT_REFSLAB_TU
+            wrs.d = wray.d;
+#endif
             wrs.ix = world.ix;
             wrs.iy = world.iy;
             wrs.iz = world.iz;

@@ -33,13 +33,20 @@ template <typename T> LPRT_DEV RayT<T> transform_ray(const RayT<T> &r, const M4<
 // half boxes cannot overflow, the repair is gone and a box test is 29 instructions instead of ~65.)
 template <typename T> struct RaySlab {
     V3<T> o;
+#ifdef LPRT_REFSLAB_TU
+    V3<T> d; // the reference-arithmetic variant divides by the direction itself (below)
+#endif
     float ix, iy, iz;
     uint32_t slow;   // bit k: 1/d_k is not finite (the ray does not move along axis k): the tests take the general form below
     uint32_t par;    // = slow when the stationary-axis rejection is on (SceneDev::axis_reject), else 0
     uint32_t reject; // 0: the reference's plain test only (A/B switch)
 };
 template <typename T> LPRT_DEV RaySlab<T> make_slab(const RayT<T> &r, uint32_t reject) {
+#ifdef LPRT_REFSLAB_TU
+    RaySlab<T> s{r.o, r.d, 1.0f / (float)r.d.x, 1.0f / (float)r.d.y, 1.0f / (float)r.d.z, 0u, 0u, reject};
+#else
     RaySlab<T> s{r.o, 1.0f / (float)r.d.x, 1.0f / (float)r.d.y, 1.0f / (float)r.d.z, 0u, 0u, reject};
+#endif
     s.slow = (__builtin_isfinite(s.ix) ? 0u : 1u) | (__builtin_isfinite(s.iy) ? 0u : 2u) | (__builtin_isfinite(s.iz) ? 0u : 4u);
     s.par = reject ? s.slow : 0u;
     return s;
@@ -77,9 +84,74 @@ template <> LPRT_DEV float dot3_f32<h16>(h16 a0, h16 a1, h16 a2, h16 b0, h16 b1,
     return __builtin_fmaf((float)a2, (float)b2, __builtin_fmaf((float)a1, (float)b1, (float)a0 * (float)b0));
 }
 
+#ifdef LPRT_REFSLAB_TU
+// ---- the reference's half slab tests, operation for operation (namespace refslab, LPRT_OPT_REFERENCE_SLAB) ------------
+// ray_aabb_intersection_scene / _object (cuda.hpp:70-149) with DataT = float16 (number.hpp:20-86): t1 = (lower - source) /
+// direction and t2 = (upper - source) / direction are a half subtraction and a half division each (one rounding per
+// operation), the pairs are ordered, axes with a non-finite t1 or t2 are ignored, entry = max / exit = min over the rest,
+// and the slack expressions `t2min * DataT(1.001953f)` / `t2min + DataT(0.02f)` are half operations as well.  A parameter
+// beyond 65504 is +-inf in half and takes its axis out of the test, exactly as in the reference.
+// Two rejections are added that cannot change a result, only the time a hopeless ray takes (they reject boxes that hold
+// no triangle the ray's triangle tests could accept): the stationary-axis rejection of the default variant, and for axes
+// lost to OVERFLOW the round-1 repair -- the lost axis is re-evaluated in f32 against the box widened by 1/8 of its extent.
+template <bool SCENE> LPRT_DEV bool slab_test_reference_half(const h16 *lo, const h16 *hi, const RaySlab<h16> &rs, float &tmn, float &tmx) {
+    const h16 d[3] = {rs.d.x, rs.d.y, rs.d.z}, o[3] = {rs.o.x, rs.o.y, rs.o.z};
+    h16 t1max = (h16)0, t2min = (h16)0;
+    bool updated = false, ok[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        h16 a = tdiv<h16>((h16)(lo[k] - o[k]), d[k]), b = tdiv<h16>((h16)(hi[k] - o[k]), d[k]);
+        if (b < a) { // swap_to_ordered
+            const h16 c = a;
+            a = b;
+            b = c;
+        }
+        ok[k] = tfinite(a) && tfinite(b);
+        if (!ok[k])
+            continue;
+        if (!updated || t1max < a)
+            t1max = a;
+        if (!updated || b < t2min)
+            t2min = b;
+        updated = true;
+    }
+    tmn = (float)t1max;
+    tmx = (float)t2min;
+    if (!updated)
+        return false;
+    if (rs.par && stationary_reject(lo, hi, rs))
+        return false;
+    if (rs.reject && !(ok[0] & ok[1] & ok[2])) {
+        const float inv[3] = {rs.ix, rs.iy, rs.iz};
+        float tn = tmn, tf = tmx;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            if (ok[k] || ((rs.slow >> k) & 1u))
+                continue; // kept by the half test, or stationary (handled above)
+            const float l = (float)lo[k], h = (float)hi[k];
+            const float m = (h - l) * 0.125f + (__builtin_fabsf(l) + __builtin_fabsf(h)) * 0.0078125f + 1e-6f;
+            const float ta = (l - m - (float)o[k]) * inv[k], tb = (h + m - (float)o[k]) * inv[k];
+            tn = __builtin_fmaxf(tn, __builtin_fminf(ta, tb));
+            tf = __builtin_fminf(tf, __builtin_fmaxf(ta, tb));
+        }
+        if (tf < -1e-3f || tn > tf * 1.002f + 0.02f)
+            return false;
+    }
+    if (SCENE) {
+        const h16 s = t2min + (h16)0.02f;
+        return t1max <= s && 0.0f <= (float)s;
+    }
+    return t1max <= (h16)(t2min * (h16)1.001953f) && 0.0f <= (float)t2min;
+}
+#endif
+
 // All six parameters finite (every ray that moves along all three axes: a product with a finite reciprocal can overflow to
 // +-inf, consistently signed, but never to NaN): entry = max3(min, min, min), exit = min3(max, max, max).
 template <typename T, bool SCENE> LPRT_DEV bool slab_test_moving(const T *lo, const T *hi, const RaySlab<T> &rs, float &tmn, float &tmx) {
+#ifdef LPRT_REFSLAB_TU
+    if constexpr (Num<T>::is_half)
+        return slab_test_reference_half<SCENE>(lo, hi, rs, tmn, tmx);
+#endif
     const float a0 = slab_t(lo[0], rs.o.x, rs.ix), b0 = slab_t(hi[0], rs.o.x, rs.ix);
     const float a1 = slab_t(lo[1], rs.o.y, rs.iy), b1 = slab_t(hi[1], rs.o.y, rs.iy);
     const float a2 = slab_t(lo[2], rs.o.z, rs.iz), b2 = slab_t(hi[2], rs.o.z, rs.iz);
@@ -96,6 +168,10 @@ template <typename T, bool SCENE> LPRT_DEV bool slab_test_moving(const T *lo, co
 // General form: axes whose entry/exit is not finite are ignored (parallel rays), as in the reference; entry = max over the
 // remaining axes, exit = min (the reference's sequential update computes exactly these extrema).
 template <typename T, bool SCENE> LPRT_DEV bool slab_test_general(const T *lo, const T *hi, const RaySlab<T> &rs, float &tmn, float &tmx) {
+#ifdef LPRT_REFSLAB_TU
+    if constexpr (Num<T>::is_half)
+        return slab_test_reference_half<SCENE>(lo, hi, rs, tmn, tmx);
+#endif
     const float a0 = slab_t(lo[0], rs.o.x, rs.ix), b0 = slab_t(hi[0], rs.o.x, rs.ix);
     const float a1 = slab_t(lo[1], rs.o.y, rs.iy), b1 = slab_t(hi[1], rs.o.y, rs.iy);
     const float a2 = slab_t(lo[2], rs.o.z, rs.iz), b2 = slab_t(hi[2], rs.o.z, rs.iz);

@@ -9,6 +9,7 @@
 namespace lprt {
 
 // ---- lprt_trace_rays: cast_ray<find_any,false> over a batch (cuda.hpp:622-631) -------------------------
+LPRT_VAR_BEGIN
 template <typename T, bool ANY, bool COUNT, bool WIDE>
 __global__ void __launch_bounds__(256) k_trace_rays(SceneDev<T> sc, const lprt_ray *rays, uint32_t n, lprt_hit *hits, Counters *counters) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -54,8 +55,13 @@ void launch_trace_rays(hipStream_t st, const SceneDev<T> &sc, const lprt_ray *ra
     else
         launch_trace_rays_w<T, false, false>(st, sc, rays, n, hits, counters);
 }
+#ifndef LPRT_REFSLAB_TU
 template void launch_trace_rays<float>(hipStream_t, const SceneDev<float> &, const lprt_ray *, uint32_t, bool, bool, lprt_hit *, Counters *);
+#endif
 template void launch_trace_rays<h16>(hipStream_t, const SceneDev<h16> &, const lprt_ray *, uint32_t, bool, bool, lprt_hit *, Counters *);
+LPRT_VAR_END
+
+#ifndef LPRT_REFSLAB_TU // everything below exists once
 
 // ---- material conversion (CUDAMaterial in DataT); objects and lights are converted by k_build_tlas (scene_dev.hpp) ----
 template <typename T> __global__ void k_convert_materials(const lprt_material *in, MaterialT<T> *out, uint32_t n) {
@@ -134,6 +140,16 @@ __global__ void k_sample_texture(const Texture *textures, const float *lut, uint
 void launch_sample_texture(hipStream_t st, const Texture *textures, const float *lut, uint32_t handle, const float *uv, uint32_t n, float *rgba) {
     hipLaunchKernelGGL(k_sample_texture, dim3((n + 255) / 256), dim3(256), 0, st, textures, lut, handle, uv, n, rgba);
 }
+__global__ void k_fmath(int op, const float *in, uint32_t n, float *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const float x = in[i];
+    out[i] = op == 0 ? lprt_logf(x) : op == 1 ? lprt_sinf(x) : op == 2 ? lprt_cosf(x) : lprt_tanf(x);
+}
+void launch_fmath(hipStream_t st, int op, const float *in, uint32_t n, float *out) {
+    hipLaunchKernelGGL(k_fmath, dim3((n + 255) / 256), dim3(256), 0, st, op, in, n, out);
+}
 
 #define INST(T)                                                                                                        \
     template void launch_make_objrecs<T>(hipStream_t, const ObjSlot<T> *, const ObjConst<T> *, const BlasInfo *, const T *, uint32_t, uint32_t,    \
@@ -142,5 +158,7 @@ void launch_sample_texture(hipStream_t st, const Texture *textures, const float 
 INST(float)
 INST(h16)
 #undef INST
+
+#endif // LPRT_REFSLAB_TU
 
 } // namespace lprt

@@ -54,6 +54,7 @@ SYMBOLS = [
     ("lprt_export_history_rows", C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32, _P]),
     ("lprt_import_history_rows", C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32, _P]),
     ("lprt_debug_sample_texture", C.c_int, [_P, C.c_uint32, _P, C.c_uint32, _P]),
+    ("lprt_debug_fmath", C.c_int, [_P, C.c_int, _P, C.c_uint32, _P]),
     ("lprt_debug_rng_states", C.c_int, [_P, C.c_uint64, C.c_uint32, C.c_uint32, _P, C.c_size_t]),
     ("lprt_set_option", C.c_int, [_P, C.c_int, C.c_int]),
     ("lprt_get_option", C.c_int, [_P, C.c_int, C.POINTER(C.c_int)]),
@@ -315,6 +316,13 @@ class Renderer:
 
     def import_history_rows(self, first_row, n_rows, dev_ptr, groups=abi.HIST_ALL):
         self._check(self.L.lprt_import_history_rows(self.h, groups, first_row, n_rows, C.c_void_p(int(dev_ptr))), "lprt_import_history_rows")
+
+    def fmath(self, op, x):
+        """include/lprt_fmath.h as the device evaluates it (test hook): op in ('log', 'sin', 'cos', 'tan')."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = _out(x.shape, np.float32)
+        self._check(self.L.lprt_debug_fmath(self.h, ("log", "sin", "cos", "tan").index(op), _ptr(x), x.size, _ptr(out)), "lprt_debug_fmath")
+        return out
 
     def rng_states(self, seed, first, count):
         out = _out((count, abi.RNG_STATE_WORDS), np.uint32)

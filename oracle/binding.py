@@ -40,6 +40,7 @@ def lib():
         L.orc_create.argtypes = [C.c_int, C.c_uint32, C.c_uint32]
         L.orc_destroy.argtypes = [C.c_void_p]
         L.orc_set_threads.argtypes = [C.c_void_p, C.c_int]
+        L.orc_set_tie_order.argtypes = [C.c_void_p, C.c_int]
         L.orc_upload_geometry.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
                                           C.c_uint32]
         L.orc_upload_materials.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
@@ -52,6 +53,8 @@ def lib():
         L.orc_read_buffer.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         L.orc_trace_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
         L.orc_get_counters.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_fmath.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.orc_fmath.restype = None
         L.orc_reset_counters.argtypes = [C.c_void_p]
         L.orc_get_stage_seconds.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_reset_stage_seconds.argtypes = [C.c_void_p]
@@ -103,6 +106,14 @@ _LIVE = weakref.WeakSet()
 def close_all():
     for o in list(_LIVE):
         o.close()
+
+
+def fmath(op, x):
+    """include/lprt_fmath.h as the host evaluates it: op in ('log', 'sin', 'cos', 'tan')."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty_like(x)
+    lib().orc_fmath(("log", "sin", "cos", "tan").index(op), _ptr(x), x.size, _ptr(out))
+    return out
 
 
 class Oracle:
@@ -187,6 +198,14 @@ class Oracle:
         rc = self.L.orc_read_buffer(self.h, bid, _ptr(out), out.size)
         assert rc == 0, rc
         return out
+
+    def set_tie_order(self, mode):
+        """Which of two triangles with equal split keys goes left in the BLAS build (render.hpp: tie_order); before load_scene."""
+        assert self.L.orc_set_tie_order(self.h, int(mode)) == 0
+
+    def trace_exhaustive(self, rays):
+        """Closest hits by the reference's triangle test against every triangle, no boxes (the yardstick for disputed hits)."""
+        return self.trace(rays, 2)
 
     def trace(self, rays, find_any=False):
         rays = np.ascontiguousarray(rays, dtype=abi.RAY_DTYPE)

@@ -368,10 +368,12 @@ inline float xorwow_normal(XorwowState &s) { // curand_normal: Box-Muller, secon
     uint32_t y = xorwow_next(s);
     float u = float(x) * 2.3283064e-10f + (2.3283064e-10f / 2.0f);
     float v = float(y) * 1.46291807e-09f + (1.46291807e-09f / 2.0f); // 2*pi*2^-32
-    float r = std::sqrt(-2.0f * std::log(u));
-    s.boxmuller_extra = r * std::cos(v);
+    // the transcendentals that shape rays come from include/lprt_fmath.h on both sides (see its header)
+    float r = std::sqrt(-2.0f * lprt_logf(u)), sn, cs;
+    lprt_sincosf(v, &sn, &cs);
+    s.boxmuller_extra = r * cs;
     s.boxmuller_flag = 1;
-    return r * std::sin(v);
+    return r * sn;
 }
 
 } // namespace orc

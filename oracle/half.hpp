@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include "../include/lprt_fmath.h" // the transcendentals that shape rays, shared with the device code (see its header)
 
 namespace orc {
 
@@ -103,7 +104,7 @@ struct half {
 };
 
 // number.hpp:132-155
-inline half tan(half v) { return half(std::tan(float(v))); }
+inline half tan(half v) { return half(lprt_tanf(float(v))); } // only use: tan(fovy / 2) of the primary rays
 inline half pow(half v, half p) { return half(std::pow(float(v), float(p))); }
 inline half abs(half v) {
     half r;
@@ -116,7 +117,7 @@ inline bool isnan(half v) { return (v.bits & 0x7c00u) == 0x7c00u && (v.bits & 0x
 
 // float counterparts with the names the pipeline code uses unqualified (CUDA device overloads
 // resolve tan/pow/abs/sqrt/exp on float to the single-precision functions).
-inline float tan(float v) { return std::tan(v); }
+inline float tan(float v) { return lprt_tanf(v); }
 inline float pow(float v, float p) { return std::pow(v, p); }
 inline float abs(float v) { return std::fabs(v); }
 inline float sqrt(float v) { return std::sqrt(v); }

@@ -104,7 +104,7 @@ template <typename T> int read_buffer(Renderer<T> &r, int id, float *dst, size_t
 }
 template <typename T> void trace_rays(Renderer<T> &r, const lprt_ray *rays, uint32_t n, int find_any, lprt_hit *hits) {
     std::vector<Counters> local(size_t(r.threads > 0 ? r.threads : 1));
-#pragma omp parallel for schedule(static) num_threads(r.threads)
+#pragma omp parallel for schedule(dynamic, 16) num_threads(r.threads)
     for (int64_t i = 0; i < int64_t(n); i++) {
         int tid = 0;
 #ifdef _OPENMP
@@ -117,8 +117,9 @@ template <typename T> void trace_rays(Renderer<T> &r, const lprt_ray *rays, uint
             ray.direction[k] = T(in.direction[k]);
         }
         SkipGeometry skip{in.skip_vao, in.skip_inobject_offset};
-        Intersection<T> is = find_any ? r.template cast_ray<true>(ray, skip, T(in.min_distance), T(in.max_distance), local[size_t(tid)])
-                                      : r.template cast_ray<false>(ray, skip, T(in.min_distance), T(in.max_distance), local[size_t(tid)]);
+        Intersection<T> is = find_any == 2 ? r.cast_ray_exhaustive(ray, skip, T(in.min_distance), T(in.max_distance), local[size_t(tid)])
+                             : find_any  ? r.template cast_ray<true>(ray, skip, T(in.min_distance), T(in.max_distance), local[size_t(tid)])
+                                         : r.template cast_ray<false>(ray, skip, T(in.min_distance), T(in.max_distance), local[size_t(tid)]);
         lprt_hit &h = hits[i];
         h.hit = is.hit ? 1u : 0u;
         h.inscene_objid = is.inscene_objid;
@@ -156,6 +157,14 @@ int orc_set_threads(void *p, int n) {
     if (n < 1)
         n = 1;
     if (h->f32) h->f32->threads = n; else h->f16->threads = n;
+    return 0;
+}
+// see Renderer::tie_order; before orc_upload_geometry
+int orc_set_tie_order(void *p, int mode) {
+    auto *h = static_cast<Handle *>(p);
+    if (mode < 0 || mode > 2)
+        return LPRT_ERR_INVALID;
+    if (h->f32) h->f32->tie_order = mode; else h->f16->tie_order = mode;
     return 0;
 }
 int orc_upload_geometry(void *p, const lprt_vertex *vbo, uint32_t nv, const uint32_t *ebo, uint32_t ni,
@@ -216,6 +225,12 @@ int orc_trace_rays(void *p, const lprt_ray *rays, uint32_t n, int find_any, lprt
     auto *h = static_cast<Handle *>(p);
     if (h->f32) trace_rays(*h->f32, rays, n, find_any, hits); else trace_rays(*h->f16, rays, n, find_any, hits);
     return 0;
+}
+// include/lprt_fmath.h as the HOST evaluates it (op 0 logf, 1 sinf, 2 cosf, 3 tanf): tests compare accuracy against
+// double-precision libm here and bit-equality against the device's evaluation (lprt_debug_fmath)
+void orc_fmath(int op, const float *in, uint32_t n, float *out) {
+    for (uint32_t i = 0; i < n; i++)
+        out[i] = op == 0 ? lprt_logf(in[i]) : op == 1 ? lprt_sinf(in[i]) : op == 2 ? lprt_cosf(in[i]) : lprt_tanf(in[i]);
 }
 int orc_get_counters(void *p, lprt_counters *out) {
     auto *h = static_cast<Handle *>(p);

@@ -239,6 +239,12 @@ template <typename T> class Renderer {
   public:
     uint32_t W = 0, H = 0;
     int threads = 1;
+    // Which of two triangles with EQUAL split keys goes left (object_bvh.hpp:122-125 leaves that to std::nth_element, whose
+    // arrangement among equal keys is implementation-defined -- the reference was built with MSVC's).  0: whatever
+    // libstdc++'s nth_element does; 1: the lower primitive index first; 2: the higher index first.  1 and 2 are two LEGAL
+    // reference topologies; comparing them measures how much of a half-precision frame the topology alone decides
+    // (tests: the oracle-vs-oracle baseline of the fp16 parity bounds).  Must be set before upload_geometry.
+    int tie_order = 0;
 
     // ---- resources (RDResource, memory.hpp:568-648) ----
     std::vector<RDVertex<T>> vbo;
@@ -522,8 +528,12 @@ template <typename T> class Renderer {
             else if (width[2] > width[0] && width[2] > width[1])
                 axis = 2;
             size_t split = size / 2;
+            const int tie = tie_order;
             std::nth_element(begin, begin + split, end, [&](uint32_t x, uint32_t y) {
-                return positions_src[indices[x]][int(axis)] < positions_src[indices[y]][int(axis)];
+                const float kx = positions_src[indices[x]][int(axis)], ky = positions_src[indices[y]][int(axis)];
+                if (tie == 0 || kx != ky)
+                    return kx < ky;
+                return tie == 1 ? x < y : x > y;
             });
             uint32_t lc = build_object_rec(out, begin, begin + split, indices, index);
             out.nodes[index].a = lc;
@@ -860,6 +870,27 @@ template <typename T> class Renderer {
                     last = cur;
                     cur = node.parent;
                 }
+            }
+        }
+        return isect;
+    }
+
+    // Exhaustive closest hit: the reference's triangle test (T3) against EVERY triangle of EVERY instance, no boxes.  Not a
+    // reference function -- the yardstick for hits that two hierarchies report differently: a traversal can only LOSE
+    // candidates (box culls), so whatever cast_ray finds over any tree has t >= this one's, and the answer that equals it
+    // is the better one (adjudicate `cull` / `tie` mismatches against a brute-force intersection).
+    Intersection<T> cast_ray_exhaustive(const Ray<T> &ray, SkipGeometry skip, T min_distance, T max_distance, Counters &cnt) const {
+        Intersection<T> isect;
+        for (uint32_t id = 0; id < objects.size(); id++) {
+            const ObjectConstant<T> &oc = objects[id];
+            if (oc.objectid >= vaos.size())
+                continue;
+            const Ray<T> lr = ray.transformed(oc.transform_W2L);
+            const uint32_t n = vaos[oc.objectid].ebo_length;
+            for (uint32_t off = 0; off + 2 < n; off += 3) {
+                if (off == skip.inobject_offset && oc.objectid == skip.vao_index)
+                    continue;
+                ray_triangle(lr, id, oc.objectid, off, isect, min_distance, max_distance, cnt);
             }
         }
         return isect;

@@ -87,32 +87,3 @@ def rel_l2(a, b):
     b = np.nan_to_num(np.asarray(b, dtype=np.float64), nan=0.0, posinf=0.0, neginf=0.0)
     den = np.linalg.norm(b)
     return float(np.linalg.norm(a - b) / den) if den > 0 else float(np.linalg.norm(a - b))
-
-
-# ---- diagnostic (LPRT_CHECK_NODEIDS=1): after every test, verify that the session's node-id strings are intact ----------
-# One GPU session in ~8 ends, all tests passed, with a SIGSEGV while pytest's cache plugin JSON-encodes its node-id list
-# (DESIGN.md 6.1).  This hook finds the test after which that memory first changes.
-_NODEID_SUMS = {}
-
-
-def pytest_collection_finish(session):
-    if os.environ.get("LPRT_CHECK_NODEIDS"):
-        import zlib
-        for item in session.items:
-            _NODEID_SUMS[id(item)] = (item.nodeid, zlib.crc32(item.nodeid.encode()), len(item.nodeid))
-        nf = session.config.pluginmanager.get_plugin("nfplugin")  # the very strings the cache plugin encodes at the end
-        for s in (getattr(nf, "cached_nodeids", None) or ()):
-            _NODEID_SUMS[id(s)] = (s, zlib.crc32(s.encode()), len(s))
-
-
-def pytest_runtest_logfinish(nodeid, location):
-    if not _NODEID_SUMS:
-        return
-    import zlib
-    with open(os.path.join(ROOT, "gpurun_out", "nodeid_check.log"), "a") as f:
-        f.write(f"after {nodeid}\n")
-        f.flush()
-        for s, crc, n in _NODEID_SUMS.values():
-            if len(s) != n or zlib.crc32(s.encode(errors="replace")) != crc:
-                f.write(f"  CORRUPTED node id (length {len(s)} vs {n})\n")
-                f.flush()

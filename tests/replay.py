@@ -164,10 +164,50 @@ def classify(r, o, sc, prec, probe_g, probe_o, frame, spp, rebuild_blas=0):
         res["gi_other_ray"].append(d & ~same_ray)
         res["gi_cull"].append(d & same_ray & ~same_t)
         res["shadow1"].append((g["shadow1"][s] != c["shadow1"][s]) | (g["shadow1_mask"][s] != c["shadow1_mask"][s]))
+    res["sides"] = (g, c)  # everything both sides' rays found (for adjudicate())
     res["n_rays"] = g["n_rays"]
     res["any"] = res["primary"] | res["shadow0"] | np.any(res["gi"], axis=0) | np.any(res["shadow1"], axis=0)
     res["last_sample"] = res["primary"] | res["shadow0"] | res["gi"][-1] | res["shadow1"][-1]
     return res
+
+
+def adjudicate(o, rays, hg, ho):
+    """Who is right where two closest-hit answers differ?  A traversal can only LOSE candidates -- a box test that rejects a box
+    the ray does pass -- never invent one: every reported hit is a triangle the reference's triangle test accepts.  So the
+    exhaustive search (Oracle.trace_exhaustive: that test against every triangle, no boxes) gives the smallest t any
+    hierarchy could report, and an answer whose t equals it is a nearest hit; one with a larger t lost the nearest
+    triangle to a cull.  rays / hg / ho: the disputed rays and the two answers (flat arrays).  Returns boolean arrays:
+      gpu_nearest, oracle_nearest   the answer's t is the exhaustive t (or both say miss);
+    (both set: an exact-t tie between two triangles; neither: both walks lost it)."""
+    e = o.trace_exhaustive(rays)
+
+    def nearest(h):
+        return ((h["hit"] == 0) & (e["hit"] == 0)) | ((h["hit"] == 1) & (e["hit"] == 1) & (h["t"] == e["t"]))
+
+    return {"gpu_nearest": nearest(hg), "oracle_nearest": nearest(ho), "exhaustive": e}
+
+
+def adjudicate_gi(c, o, kinds=("gi_cull", "gi_tie")):
+    """The disputed closest-hit rays of a classified frame (bit-identical ray on both sides, different answer), every
+    sample, adjudicated by exhaustive search on oracle `o`.  Returns counts: disputed, gpu_nearest, oracle_nearest,
+    gpu_lost (the oracle reports the nearest hit and the GPU a farther one), oracle_lost, neither."""
+    g, cc = c["sides"]
+    tot = dict(disputed=0, gpu_nearest=0, oracle_nearest=0, gpu_lost=0, oracle_lost=0, neither=0)
+    for s in range(len(c["gi"])):
+        m = np.zeros_like(c["gi"][s])
+        for k in kinds:
+            m |= c[k][s]
+        if not m.any():
+            continue
+        j = adjudicate(o, g["gi_rays"][s][m], g["gi"][s][m], cc["gi"][s][m])
+        gn, on = j["gpu_nearest"], j["oracle_nearest"]
+        tot["disputed"] += int(m.sum())
+        tot["gpu_nearest"] += int(gn.sum())
+        tot["oracle_nearest"] += int(on.sum())
+        tot["gpu_lost"] += int((~gn & on).sum())
+        tot["oracle_lost"] += int((gn & ~on).sum())
+        tot["neither"] += int((~gn & ~on).sum())
+    return tot
 
 
 def dilate(mask, radius):

@@ -18,10 +18,24 @@ RADIANCE = ["INTENSITY0", "INTENSITY1", "RAW_COLOR", "RAW_GI_COLORED", "RAW_GI_W
             "COLOR_INPROGRESS", "OUTPUT"]
 
 
-def render_pair(sc, W, H, prec, frames=1, **kw):
+# Half precision runs in both slab modes (LPRT_OPT_REFERENCE_SLAB, include/lprt.h): 0 = the product's default (slab parameters
+# of half boxes in f32: the GPU never culls a box the ray reaches), 1 = ray_aabb_intersection_* in float16 operation for
+# operation as the reference (its own lossy test).  Single precision has one mode: its arithmetic is the reference's.
+PREC_SLAB = [(abi.F32, 0), (abi.F16, 0), (abi.F16, 1)]
+PREC_SLAB_IDS = ["f32", "f16", "f16-refslab"]
+
+
+def renderer(W, H, prec, slab=0, **kw):
+    r = lprt_amd.Renderer(W, H, prec, **kw)
+    if slab:
+        r.set_option("reference_slab", slab)
+    return r
+
+
+def render_pair(sc, W, H, prec, frames=1, slab=0, **kw):
     o = Oracle(W, H, prec)
     o.load_scene(sc)
-    r = lprt_amd.Renderer(W, H, prec)
+    r = renderer(W, H, prec, slab)
     r.load_scene(sc)
     for _ in range(frames):
         fs = abi.default_settings(**kw)
@@ -32,10 +46,10 @@ def render_pair(sc, W, H, prec, frames=1, **kw):
     return r, o
 
 
-@pytest.mark.parametrize("prec", [abi.F32, abi.F16])
-def test_c1_golden_cornell_256(cornell, prec):
+@pytest.mark.parametrize("prec,slab", PREC_SLAB, ids=PREC_SLAB_IDS)
+def test_c1_golden_cornell_256(cornell, prec, slab):
     """BASELINE configs[0] on the GPU against the committed oracle vectors (fp32) / live oracle (fp16)."""
-    r = lprt_amd.Renderer(256, 256, prec)
+    r = renderer(256, 256, prec, slab)
     r.load_scene(cornell)
     r.render(abi.default_settings(spp=1))
     if prec == abi.F32:
@@ -73,9 +87,9 @@ def assert_planes_ray_by_ray(r, o, c, prec, kept_l2, kept_px, max_outliers):
             assert rel_l2(r.read(name), o.read(name)) < TOL[prec], name
 
 
-@pytest.mark.parametrize("prec", [abi.F32, abi.F16])
+@pytest.mark.parametrize("prec,slab", PREC_SLAB, ids=PREC_SLAB_IDS)
 @pytest.mark.parametrize("scene_name,W,H", [("cornell", 160, 96), ("small_test", 200, 120), ("textured", 192, 108), ("instanced_field", 160, 90)])
-def test_every_buffer_matches_oracle(scene_name, W, H, prec):
+def test_every_buffer_matches_oracle(scene_name, W, H, prec, slab):
     """One frame, every plane.  Single precision: integer planes bit-exact, every radiance plane within 1e-3 over ALL pixels
     (no ray of these scenes finds anything else than in the oracle).  Half precision: a few rays per frame do (primary
     rays at silhouettes, GI rays whose direction differs in its last bit, ties at half resolution of t: 0.1 % of the pixels
@@ -83,7 +97,7 @@ def test_every_buffer_matches_oracle(scene_name, W, H, prec):
     number is bounded, and every other pixel of the pre-denoise planes agrees to 1e-4 -- where the rays agree, the
     arithmetic does."""
     sc = scenes.SCENES[scene_name]()
-    r, o = render_pair(sc, W, H, prec, frames=1, spp=1)
+    r, o = render_pair(sc, W, H, prec, frames=1, slab=slab, spp=1)
     if prec == abi.F32:  # integer planes bit-exact
         for name in ("G_OBJID", "G_OFFSET", "G_COLOR"):
             assert np.array_equal(r.read(name), o.read(name)), name
@@ -94,37 +108,59 @@ def test_every_buffer_matches_oracle(scene_name, W, H, prec):
             assert np.array_equal(np.isfinite(a), np.isfinite(b)), name
             assert rel_l2(a, b) < TOL[prec], name
         return
-    probe_g, probe_o = lprt_amd.Renderer(W, H, prec), Oracle(W, H, prec)
+    probe_g, probe_o = renderer(W, H, prec, slab), Oracle(W, H, prec)
     probe_g.load_scene(sc)
     probe_o.load_scene(sc)
     c = replay.classify(r, o, sc, prec, probe_g, probe_o, frame=0, spp=1)
     assert c["any"].mean() < 2.5e-3, int(c["any"].sum())
     assert sum(int(m.sum()) for m in c["gi_cull"]) <= 2
+    # since the transcendentals that shape rays are shared (include/lprt_fmath.h) two implementations that agree on the
+    # primary hit cast the bit-identical GI ray: an `other ray` can only follow from a primary ray that found something else
+    assert not (c["gi_other_ray"][0] & ~c["primary"]).any()
     assert_planes_ray_by_ray(r, o, c, prec, kept_l2=1e-4, kept_px=1e-2, max_outliers=0)
     assert rel_l2(r.read("OUTPUT"), o.read("OUTPUT")) < TOL[prec]  # what is displayed, over all pixels
 
 
-@pytest.mark.parametrize("prec", [abi.F32, abi.F16])
-def test_atrium_frames_with_per_frame_rebuild_match_oracle_ray_by_ray(sponza, prec):
-    """BASELINE configs[3] workload (262 k-triangle atrium, every BLAS rebuilt on the GPU inside each frame) against the
-    oracle: two frames at 2 spp, reduced to 256x144 so the oracle finishes in seconds.
+# Whole-buffer ceilings of the atrium's half-precision frames (relative L2 over ALL pixels, HIP vs oracle), recorded from
+# the round-3 run (gpurun_out/r3_probe1.log: measured maxima over both frames and both slab modes in brackets) with ~1.4x
+# headroom, so that drift is caught.  They are NOT the north star's 5e-2: on this workload the oracle misses that bar
+# against ITSELF when only the order of equal split keys changes (tests/golden/topology_baseline_sponza_f16.json,
+# tools/oracle_topology_baseline.py: INTENSITY1 0.14, RAW_GI_COLORED 0.066, MUL_GI_WHITE 0.050) -- one sample of one-bounce
+# radiance is a few bright pixels, and in half precision which triangle wins at the "same" t depends on the hierarchy.
+ATRIUM_F16_CEILING = {"INTENSITY0": 0.025, "INTENSITY1": 0.25, "RAW_COLOR": 0.025, "RAW_GI_COLORED": 0.10, "RAW_GI_WHITE": 0.30,
+                      "MUL_GI_COLORED": 0.085, "MUL_GI_WHITE": 0.12, "COLOR_INPROGRESS": 0.036, "OUTPUT": 0.005}
+#                      [0.017, 0.175, 0.017, 0.071, 0.213, 0.060, 0.083, 0.025, 0.0035]
 
-    The atrium is where rays can legally find something else than in the oracle: its GI directions come out of device
-    transcendentals that differ from libm in the last bit (a different ray), and in half precision t has 11 bits at
-    distances of 5-30 m, so which of several triangles at the "same" t wins depends on traversal order, which depends on
-    the hierarchy (the reference leaves that to std::nth_element).  Every ray of every sample is therefore replayed on both
-    sides (tests/replay.py, ~320 k rays per frame) and the claim is split in two:
-      1. how many pixels see a ray that found something else, by kind -- bounded; in single precision a handful (all of the
-         `other ray` kind, none from box culling), in half precision a few per cent;
-      2. everywhere else the pre-denoise radiance planes agree to 2e-4 (fp32: libm vs device rounding) / 1e-4 (fp16),
-         i.e. the arithmetic is the oracle's.
-    What is displayed (OUTPUT, COLOR_INPROGRESS) meets the north star's whole-buffer tolerance over all pixels."""
+
+@pytest.mark.parametrize("prec,slab", PREC_SLAB, ids=PREC_SLAB_IDS)
+def test_atrium_frames_with_per_frame_rebuild_match_oracle_ray_by_ray(sponza, prec, slab):
+    """BASELINE configs[3] workload (262 k-triangle atrium, every BLAS rebuilt on the GPU inside each frame) against the
+    oracle: two frames at 2 spp, reduced to 256x144 so the oracle finishes in seconds.  Every ray of every sample is
+    replayed on both sides (tests/replay.py, ~320 k rays per frame).
+
+    Single precision: every radiance plane within 1e-3 over ALL pixels, nothing set aside.  The transcendentals that
+    shape rays are shared with the oracle (include/lprt_fmath.h), so both sides cast bit-identical rays: no `other ray`, no
+    `cull`; what remains are exact-t ties between coplanar triangles, a handful of pixels.
+
+    Half precision: which triangle a ray reports depends on the hierarchy (t has 11 bits at 5-30 m; the reference's half
+    slab test culls boxes the ray does pass, and which ones depends on the tree std::nth_element happens to build).  The
+    statement therefore has four parts, in both slab modes:
+      1. per class, the pixels where HIP and oracle disagree are at most 1.25x (primary, GI, all) / 2x (culls, shadow rays:
+         the GPU's tree differs from the oracle's by more than a tie order) what the ORACLE disagrees with ITSELF under two
+         legal tie orders of the reference's builder (committed baseline, tests/golden/topology_baseline_sponza_f16.json);
+      2. disputed closest hits adjudicated by exhaustive search (replay.adjudicate_gi): the GPU reports a farther hit than
+         the oracle no more often than the reverse -- a lost pending bit or a missed box would show up here;
+      3. every other pixel of the pre-denoise planes agrees to 1e-4: where the rays agree, the arithmetic does;
+      4. every radiance plane over ALL pixels under a recorded ceiling; OUTPUT and COLOR_INPROGRESS under the north star's."""
+    import json
     W, H, spp = 256, 144, 2
     o, probe_o = Oracle(W, H, prec), Oracle(W, H, prec)
-    r, probe_g = lprt_amd.Renderer(W, H, prec), lprt_amd.Renderer(W, H, prec)
+    r, probe_g = renderer(W, H, prec, slab), renderer(W, H, prec, slab)
     for x in (o, probe_o, r, probe_g):
         x.load_scene(sponza)
-    npx = W * H
+    with open(os.path.join(GOLD, "topology_baseline_sponza_f16.json")) as fh:
+        base = json.load(fh)
+    assert base["size"] == [W, H] and base["spp"] == spp
     for f in range(2):
         fs = abi.default_settings(spp=spp)
         fs.rebuild_blas = 1
@@ -135,19 +171,30 @@ def test_atrium_frames_with_per_frame_rebuild_match_oracle_ray_by_ray(sponza, pr
         c = replay.classify(r, o, sponza, prec, probe_g, probe_o, f, spp, rebuild_blas=1)
         count = lambda k: max(int(m.sum()) for m in c[k])
         if prec == abi.F32:
-            assert int(c["primary"].sum()) <= 2 and int(c["shadow0"].sum()) <= 2
             assert count("gi_cull") == 0, "identical rays at different t: a traversal bug, not a tie"
-            assert count("gi") <= 8 and count("shadow1") <= 8 and int(c["any"].sum()) <= 16
-            assert_planes_ray_by_ray(r, o, c, prec, kept_l2=2e-4, kept_px=1e-2, max_outliers=3)
-            for name in ("INTENSITY0", "RAW_COLOR", "MUL_GI_COLORED", "MUL_GI_WHITE", "COLOR_INPROGRESS", "OUTPUT"):
-                assert rel_l2(r.read(name), o.read(name)) < TOL[prec], (f, name)  # over all pixels
-        else:
-            assert c["primary"].mean() < 0.025 and c["shadow0"].mean() < 3e-3
-            assert count("gi") < 0.025 * npx and count("gi_cull") < 5e-3 * npx and count("shadow1") < 5e-3 * npx
-            assert c["any"].mean() < 0.05
-            assert_planes_ray_by_ray(r, o, c, prec, kept_l2=1e-4, kept_px=1e-2, max_outliers=0)
-            for name in ("COLOR_INPROGRESS", "OUTPUT"):
-                assert rel_l2(r.read(name), o.read(name)) < TOL[prec], (f, name)
+            assert count("gi_other_ray") == 0, "the two sides cast different rays"
+            assert int(c["primary"].sum()) <= 2 and int(c["shadow0"].sum()) <= 2
+            assert count("gi") <= 6 and count("shadow1") <= 4 and int(c["any"].sum()) <= 10
+            for name in RADIANCE:  # over ALL pixels, nothing set aside
+                a, b = r.read(name), o.read(name)
+                assert np.array_equal(np.isfinite(a), np.isfinite(b)), (f, name)
+                assert rel_l2(a, b) < TOL[prec], (f, name, rel_l2(a, b))
+            continue
+        b = base["frames"][f]["px"]
+        got = {"primary": int(c["primary"].sum()), "gi": count("gi"), "any": int(c["any"].sum()), "gi_cull": count("gi_cull"),
+               "shadow0": int(c["shadow0"].sum()), "shadow1": count("shadow1")}
+        for k, factor in (("primary", 1.25), ("gi", 1.25), ("any", 1.25), ("gi_cull", 2.0), ("shadow0", 2.0), ("shadow1", 2.0)):
+            ref = max(b[k]) if isinstance(b[k], list) else b[k]
+            assert got[k] <= factor * ref, (f, k, got[k], ref)
+        # an `other ray` follows from a primary ray that found something else (another source point), never from the shading
+        for s_ in range(spp):
+            assert not (c["gi_other_ray"][s_] & ~c["primary"]).any(), (f, s_)
+        j = replay.adjudicate_gi(c, probe_o)
+        assert j["neither"] <= 2 and j["gpu_lost"] <= max(8, j["oracle_lost"]), (f, j)
+        assert_planes_ray_by_ray(r, o, c, prec, kept_l2=1e-4, kept_px=1e-2, max_outliers=0)
+        for name in RADIANCE:
+            lim = min(ATRIUM_F16_CEILING[name], TOL[prec]) if name in ("COLOR_INPROGRESS", "OUTPUT") else ATRIUM_F16_CEILING[name]
+            assert rel_l2(r.read(name), o.read(name)) <= lim, (f, name, rel_l2(r.read(name), o.read(name)))
 
 
 @pytest.mark.parametrize("prec", [abi.F32, abi.F16])
@@ -200,12 +247,12 @@ def test_rebuilding_every_blas_inside_the_frame_changes_nothing(sponza, prec):
         assert np.array_equal(a, b, equal_nan=True)
 
 
-@pytest.mark.parametrize("prec", [abi.F32, abi.F16])
-def test_temporal_path_three_frames_spp2(cornell, prec):
+@pytest.mark.parametrize("prec,slab", PREC_SLAB, ids=PREC_SLAB_IDS)
+def test_temporal_path_three_frames_spp2(cornell, prec, slab):
     """frames >= 1 exercise reprojection maps, colour/moment history, frame counters (+4 per frame, Q6), TAA history."""
     o = Oracle(128, 96, prec)
     o.load_scene(cornell)
-    r = lprt_amd.Renderer(128, 96, prec)
+    r = renderer(128, 96, prec, slab)
     r.load_scene(cornell)
     for f in range(3):
         fs = abi.default_settings(spp=2)
@@ -626,7 +673,7 @@ def test_render_phases_and_sample_rows_are_checked(cornell):
 def test_options_out_array_sizes_and_null_pointers_are_checked(cornell):
     import ctypes as C
     with lprt_amd.Renderer(32, 32, abi.F32) as r:
-        assert [r.get_option(n) for n in abi.OPTIONS] == [-1, -1, 1, 0, 0, 1, 0, -1, 0, 12, 20, 0, 8, 0, 1]
+        assert [r.get_option(n) for n in abi.OPTIONS] == [-1, -1, 1, 0, 0, 1, 0, -1, 0, 12, 20, 0, 8, 0, 1, 0]
         r.set_option("wide_walk", 1)
         assert r.get_option("wide_walk") == 1
         with pytest.raises(lprt_amd.LprtError, match="out of range"):
@@ -645,19 +692,32 @@ def test_options_out_array_sizes_and_null_pointers_are_checked(cornell):
     assert r.h is None  # closed by the context manager
 
 
-@pytest.mark.parametrize("prec", [abi.F32, abi.F16])
-def test_moving_objects_and_camera_reproject_like_the_oracle(cornell, prec):
+# moving Cornell, half precision, DEFAULT slab mode: whole-buffer relative L2 (all pixels) recorded in round 3
+# (gpurun_out/r3_probe1.log part C; measured maxima over the four frames in brackets).  The pre-denoise GI planes of frame 0
+# exceed the north star's 5e-2 in this mode and ONLY in this mode: the f32 slab test admits rays to boxes the reference's
+# half test culls (turned boxes: 6-10 primary hits per frame differ), and one sample of bounce radiance is a few bright
+# pixels.  In reference-slab mode every plane of every frame is within 5e-2 (asserted below).
+MOVING_F16_CEILING = {"INTENSITY0": 0.004, "INTENSITY1": 0.11, "RAW_COLOR": 0.004, "RAW_GI_COLORED": 0.09, "RAW_GI_WHITE": 0.08,
+                      "MUL_GI_COLORED": 0.07, "MUL_GI_WHITE": 0.06, "COLOR_INPROGRESS": 0.004, "OUTPUT": 0.012}
+#                      [0.0018, 0.079, 0.0018, 0.063, 0.056, 0.050, 0.044, 0.0017, 0.0056]
+
+
+@pytest.mark.parametrize("prec,slab", PREC_SLAB, ids=PREC_SLAB_IDS)
+def test_moving_objects_and_camera_reproject_like_the_oracle(cornell, prec, slab):
     """Temporal maps under motion (cuda.hpp:2265-2416): the tall box turns, the short box slides and the camera
     dollies between frames, so reprojection goes through last-frame L2W / W2C, history taps move and some are
-    rejected on object-id mismatch."""
+    rejected on object-id mismatch.  Single precision and half precision with the reference's slab arithmetic: EVERY
+    radiance plane of every frame within the north star's tolerance over all pixels.  Half precision with the default
+    (f32) slab parameters: ray by ray, plus recorded whole-buffer ceilings."""
     import copy
     W, H = 160, 96
     o = Oracle(W, H, prec)
     o.load_scene(cornell)
-    r = lprt_amd.Renderer(W, H, prec)
+    r = renderer(W, H, prec, slab)
     r.load_scene(cornell)
-    if prec == abi.F16:
-        probe_g, probe_o = lprt_amd.Renderer(W, H, prec), Oracle(W, H, prec)
+    ray_by_ray = prec == abi.F16 and slab == 0
+    if ray_by_ray:
+        probe_g, probe_o = renderer(W, H, prec, slab), Oracle(W, H, prec)
         probe_g.load_scene(cornell)
         probe_o.load_scene(cornell)
     for k in range(4):
@@ -669,19 +729,23 @@ def test_moving_objects_and_camera_reproject_like_the_oracle(cornell, prec):
         r.render(fs)
         if prec == abi.F32:
             assert np.array_equal(r.read("G_OBJID"), o.read("G_OBJID")), k
+        if not ray_by_ray:
             for name in RADIANCE:
-                assert rel_l2(r.read(name), o.read(name)) < TOL[prec], (k, name)
+                assert rel_l2(r.read(name), o.read(name)) < TOL[prec], (k, name, rel_l2(r.read(name), o.read(name)))
         else:
-            # half precision, turned boxes: a few rays per frame find something else than in the oracle (its half slab
-            # test loses boxes the ray does pass; ties at half resolution of t).  Named ray by ray, bounded,
-            # everything else held tight; what is displayed within the north star's tolerance over all pixels.
+            # a few rays per frame find something else than in the oracle (its half slab test loses boxes the ray does
+            # pass; ties at half resolution of t).  Named ray by ray, bounded, everything else held tight;
+            # disputed closest hits adjudicated by exhaustive search; every plane under its recorded ceiling.
             c = replay.classify(r, o, sc, prec, probe_g, probe_o, frame=k, spp=1)
             assert c["any"].mean() < 5e-3, (k, int(c["any"].sum()))
+            j = replay.adjudicate_gi(c, probe_o)
+            assert j["gpu_lost"] <= max(1, j["oracle_lost"]) and j["neither"] == 0, (k, j)
             assert_planes_ray_by_ray(r, o, c, prec, kept_l2=1e-4, kept_px=1e-2, max_outliers=0)
-            for name in ("COLOR_INPROGRESS", "OUTPUT"):
-                assert rel_l2(r.read(name), o.read(name)) < TOL[prec], (k, name)
+            for name in RADIANCE:
+                lim = min(MOVING_F16_CEILING[name], TOL[prec]) if name in ("COLOR_INPROGRESS", "OUTPUT") else MOVING_F16_CEILING[name]
+                assert rel_l2(r.read(name), o.read(name)) <= lim, (k, name, rel_l2(r.read(name), o.read(name)))
     # the sequence is not the static one: history was actually reprojected
-    still = lprt_amd.Renderer(W, H, prec)
+    still = renderer(W, H, prec, slab)
     still.load_scene(cornell)
     for k in range(4):
         still.set_scene(cornell)

@@ -10,6 +10,7 @@ import pytest
 import lprt_amd
 from lprt_amd import abi, scenes
 from oracle.binding import Oracle
+import replay
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -77,6 +78,64 @@ def test_fp16_hit_records_match_oracle(scene_name):
     assert same.sum() >= 0.99 * both.sum()
     assert np.array_equal(ho["t"][same], hg["t"][same])
     assert (o.trace(rays, True)["hit"] != r.trace(rays, True)["hit"]).mean() < 1e-3
+
+
+@pytest.mark.parametrize("slab", [0, 1], ids=["f32-slab", "reference-slab"])
+def test_fp16_closest_hits_on_the_atrium_against_oracle_and_exhaustive_search(sponza, slab):
+    """Half-precision closest hits on the 262 k-triangle atrium, id and t, against the oracle -- in both slab modes
+    (LPRT_OPT_REFERENCE_SLAB: 0 = slab parameters in f32, the default; 1 = the reference's float16 arithmetic).
+
+    In half precision the answer depends on the hierarchy: the reference's slab test culls boxes the ray does pass, and t has
+    11 bits, so several triangles can sit at the "same" t.  The reference's own hierarchy is only defined up to the order
+    std::nth_element leaves equal keys in (object_bvh.hpp:122-125), so the yardstick has two parts:
+      * how often two LEGAL reference topologies disagree with each other (the oracle under tie orders 1 and 2);
+      * the exhaustive search (the reference's triangle test against every triangle, no boxes): a traversal can only lose
+        candidates, so the answer whose t equals the exhaustive t is a nearest hit.
+    HIP vs oracle: disputed rays <= 1.25x the oracle-vs-oracle count; t / barycentrics bit-equal wherever the triangle
+    agrees; on the disputed rays the GPU loses the nearest hit no more often than one reference topology loses it against
+    another; undisputed rays (a sample) are nearest hits on both sides."""
+    prec = abi.F16
+    rays = random_rays(sponza, 40000, 13, 0.1)
+    orc, ans = {}, {}
+    for tie in (0, 1, 2):
+        orc[tie] = Oracle(16, 16, prec)
+        orc[tie].set_tie_order(tie)
+        orc[tie].load_scene(sponza)
+        ans[tie] = orc[tie].trace(rays, False)
+    with lprt_amd.Renderer(16, 16, prec) as r:
+        r.set_option("reference_slab", slab)
+        r.load_scene(sponza)
+        hg = r.trace(rays, False)
+    ho = ans[0]
+    baseline = max(int(replay.closest_differs(ans[a], ans[b]).sum()) for a, b in ((0, 1), (0, 2), (1, 2)))
+    d = replay.closest_differs(hg, ho)
+    assert int((hg["hit"] != ho["hit"]).sum()) <= 12
+    assert int(d.sum()) <= 1.25 * baseline, (int(d.sum()), baseline)
+    same = ~d & (ho["hit"] == 1)
+    assert np.array_equal(hg["t"][same], ho["t"][same]) and np.array_equal(hg["barycentric"][same], ho["barycentric"][same])
+    j = replay.adjudicate(orc[0], rays[d], hg[d], ho[d])
+    gpu_lost = int((~j["gpu_nearest"] & j["oracle_nearest"]).sum())
+    neither = int((~j["gpu_nearest"] & ~j["oracle_nearest"]).sum())
+    lost_between_topologies = 0
+    for a, b in ((1, 0), (2, 0), (0, 1), (0, 2)):
+        dd = replay.closest_differs(ans[a], ans[b])
+        jj = replay.adjudicate(orc[0], rays[dd], ans[a][dd], ans[b][dd])
+        lost_between_topologies = max(lost_between_topologies, int((~jj["gpu_nearest"] & jj["oracle_nearest"]).sum()))
+    assert gpu_lost <= 1.25 * lost_between_topologies and neither <= 2, (gpu_lost, lost_between_topologies, neither)
+    idx = np.flatnonzero(~d)[:400]
+    j = replay.adjudicate(orc[0], rays[idx], hg[idx], ho[idx])
+    assert j["gpu_nearest"].all() and j["oracle_nearest"].all()
+
+
+def test_fp32_closest_hits_on_the_atrium_are_the_exhaustive_search_s(sponza):
+    """Single precision: nothing is lost to a box test -- a sample of closest hits equals the exhaustive search in t."""
+    rays = random_rays(sponza, 400, 17, 1e-4)
+    with Oracle(16, 16, abi.F32) as o, lprt_amd.Renderer(16, 16, abi.F32) as r:
+        o.load_scene(sponza)
+        r.load_scene(sponza)
+        hg = r.trace(rays, False)
+        j = replay.adjudicate(o, rays, hg, o.trace(rays, False))
+        assert j["gpu_nearest"].all() and j["oracle_nearest"].all()
 
 
 @pytest.mark.parametrize("prec", [abi.F32, abi.F16])
