@@ -319,7 +319,15 @@ int lprt_output_device_ptr(lprt_ctx *ctx, void **ptr, size_t *bytes);
 
 /* Sharded frames: besides its own output plane the context also writes image rows
  * [first_row, first_row + n_rows) of the final RGBA32F image to dst (row-major, width*4 floats per row),
- * e.g. this rank's slot of the tensor handed to the RCCL all-gather.  dst = NULL turns it off. */
+ * e.g. this rank's slot of the tensor handed to the RCCL all-gather.  dst = NULL turns it off.
+ *
+ * CONTRACT while a target is set: the target rows are what this context is asked for, so the a-trous levels of the
+ * denoiser run only on the rows that can still influence them (level l within 64 - 2^(l+2) rows of the target strip).
+ * Outside that reach the denoised planes of the window (LPRT_BUF_MUL_GI_*, LPRT_BUF_OUTPUT and the level-1 output that
+ * serves as the NEXT frame's colour history) keep what earlier frames left there: only the TARGET rows of those planes
+ * and of the context's own output plane are valid, and before the next frame the caller must import LPRT_HIST_FILTER for
+ * every window row outside the target strip from the context that owns it (lprt_import_history_rows; dist.py does so
+ * every frame).  A caller that sets a target without that exchange gets stale history on its halo rows. */
 int lprt_set_output_target(lprt_ctx *ctx, void *dst_device, uint32_t first_row, uint32_t n_rows);
 
 /* Sharded frames over several frames: the per-pixel state frame n+1 reads of frame n (SVGF colour and moment history

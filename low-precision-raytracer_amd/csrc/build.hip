@@ -875,6 +875,7 @@ template <typename T> void GeometryStore<T>::upload(hipStream_t st, const lprt_v
         hipLaunchKernelGGL(k_convert_vertices<T>, dim3((nv + 255) / 256), dim3(256), 0, st, d_vbo32.as<lprt_vertex>(),
                            d_vbo.as<Vertex<T>>(), nv);
     built = false;
+    plan_valid = false;
 }
 
 template <typename T> void GeometryStore<T>::radix_sort(hipStream_t st, const std::vector<int> &shifts, int &cur) {
@@ -890,36 +891,8 @@ template <typename T> void GeometryStore<T>::radix_sort(hipStream_t st, const st
     }
 }
 
-template <typename T> void GeometryStore<T>::build_blas(hipStream_t st, bool use_morton, bool use_local) {
-    if (n_tris == 0 || n_vaos == 0) {
-        built = true;
-        return;
-    }
-    const uint32_t tb = (n_tris + 255) / 256;
-    hipLaunchKernelGGL(k_init_bounds, dim3((6 * n_vaos + 255) / 256), dim3(256), 0, st, d_prim_cbounds.as<int>(), n_vaos);
-    hipLaunchKernelGGL(k_tri_prepare, dim3(tb), dim3(256), 0, st, d_vbo32.as<lprt_vertex>(), d_ebo.as<uint32_t>(), n_tris,
-                       d_tri_prim.as<uint32_t>(), d_mf32.as<TriRecF32>(), d_tri_bounds.as<float>(), d_prim_cbounds.as<int>());
-    int cur = 0;
-    if (use_morton) {
-        hipLaunchKernelGGL(k_morton_keys, dim3(tb), dim3(256), 0, st, d_tri_bounds.as<float>(), d_tri_prim.as<uint32_t>(),
-                           d_prim_cbounds.as<int>(), n_tris, d_keys[0].as<unsigned long long>(), d_vals[0].as<uint32_t>());
-        // radix passes over the 30 Morton bits + the primitive bits (key = prim << 32 | morton)
-        uint32_t prim_bits = 0;
-        while ((1u << prim_bits) < n_vaos)
-            prim_bits++;
-        std::vector<int> shifts = {0, 8, 16, 24};
-        for (uint32_t b = 0; b < prim_bits; b += 8)
-            shifts.push_back(32 + (int)b);
-        radix_sort(st, shifts, cur);
-    } else {
-        uint32_t pos_bits = 1;
-        while ((1ull << pos_bits) < n_tris)
-            pos_bits++;
-        std::vector<int> shifts = {0, 8};
-        for (uint32_t b = 0; b < pos_bits; b += 8)
-            shifts.push_back(16 + (int)b);
-        d_seg_bounds.reserve(sizeof(int) * 6 * (size_t)n_tris);
-        hipLaunchKernelGGL(k_iota, dim3(tb), dim3(256), 0, st, d_vals[cur].as<uint32_t>(), n_tris);
+// see build_blas: everything about the median build that is a function of the triangle counts, computed and uploaded once
+template <typename T> void GeometryStore<T>::make_plan(hipStream_t st, bool use_local) {
         // levels walked by the global sort: until every node of every primitive holds <= LOCAL_MAX triangles
         uint32_t global_levels = max_depth;
         std::vector<LocalJob> jobs;
@@ -969,8 +942,59 @@ template <typename T> void GeometryStore<T>::build_blas(hipStream_t st, bool use
         if (dense) {
             d_rank_bases.reserve(sizeof(uint32_t) * rank_bases.size());
             LPRT_HIP(hipMemcpyAsync(d_rank_bases.ptr, rank_bases.data(), sizeof(uint32_t) * rank_bases.size(), hipMemcpyHostToDevice, st));
-            LPRT_HIP(hipStreamSynchronize(st));
         }
+        plan_global_levels = global_levels;
+        plan_dense = dense;
+        plan_level_nodes = level_nodes;
+        plan_jobs = (uint32_t)jobs.size();
+        if (!jobs.empty()) {
+            d_local_jobs.reserve(sizeof(LocalJob) * jobs.size());
+            LPRT_HIP(hipMemcpyAsync(d_local_jobs.ptr, jobs.data(), sizeof(LocalJob) * jobs.size(), hipMemcpyHostToDevice, st));
+        }
+        LPRT_HIP(hipStreamSynchronize(st)); // the host vectors above go out of scope (once per upload, never inside a frame)
+        plan_local = use_local;
+        plan_valid = true;
+}
+
+template <typename T> void GeometryStore<T>::build_blas(hipStream_t st, bool use_morton, bool use_local) {
+    if (n_tris == 0 || n_vaos == 0) {
+        built = true;
+        return;
+    }
+    const uint32_t tb = (n_tris + 255) / 256;
+    hipLaunchKernelGGL(k_init_bounds, dim3((6 * n_vaos + 255) / 256), dim3(256), 0, st, d_prim_cbounds.as<int>(), n_vaos);
+    hipLaunchKernelGGL(k_tri_prepare, dim3(tb), dim3(256), 0, st, d_vbo32.as<lprt_vertex>(), d_ebo.as<uint32_t>(), n_tris,
+                       d_tri_prim.as<uint32_t>(), d_mf32.as<TriRecF32>(), d_tri_bounds.as<float>(), d_prim_cbounds.as<int>());
+    int cur = 0;
+    if (use_morton) {
+        hipLaunchKernelGGL(k_morton_keys, dim3(tb), dim3(256), 0, st, d_tri_bounds.as<float>(), d_tri_prim.as<uint32_t>(),
+                           d_prim_cbounds.as<int>(), n_tris, d_keys[0].as<unsigned long long>(), d_vals[0].as<uint32_t>());
+        // radix passes over the 30 Morton bits + the primitive bits (key = prim << 32 | morton)
+        uint32_t prim_bits = 0;
+        while ((1u << prim_bits) < n_vaos)
+            prim_bits++;
+        std::vector<int> shifts = {0, 8, 16, 24};
+        for (uint32_t b = 0; b < prim_bits; b += 8)
+            shifts.push_back(32 + (int)b);
+        radix_sort(st, shifts, cur);
+    } else {
+        uint32_t pos_bits = 1;
+        while ((1ull << pos_bits) < n_tris)
+            pos_bits++;
+        std::vector<int> shifts = {0, 8};
+        for (uint32_t b = 0; b < pos_bits; b += 8)
+            shifts.push_back(16 + (int)b);
+        d_seg_bounds.reserve(sizeof(int) * 6 * (size_t)n_tris);
+        hipLaunchKernelGGL(k_iota, dim3(tb), dim3(256), 0, st, d_vals[cur].as<uint32_t>(), n_tris);
+        // The plan of the build -- how many levels the global sort walks, the subtrees handed to k_local_levels, the dense node
+        // ranks of every level -- depends on the triangle COUNTS only: it is made once per geometry upload (and builder
+        // option) and kept on the device, so a per-frame rebuild (lprt_frame_settings.rebuild_blas) enqueues kernels and
+        // nothing else: no host staging, no stream synchronisation inside the frame.
+        if (!plan_valid || plan_local != use_local)
+            make_plan(st, use_local);
+        const uint32_t global_levels = plan_global_levels;
+        const bool dense = plan_dense;
+        const std::vector<uint32_t> &level_nodes = plan_level_nodes;
         for (uint32_t d = 0; d < global_levels; d++) {
             if (dense) {
                 uint32_t bits = 1;
@@ -988,13 +1012,9 @@ template <typename T> void GeometryStore<T>::build_blas(hipStream_t st, bool use
                                d_keys[cur].as<unsigned long long>(), dense ? d_rank_bases.as<uint32_t>() + (size_t)d * n_vaos : nullptr);
             radix_sort(st, shifts, cur);
         }
-        if (!jobs.empty()) {
-            d_local_jobs.reserve(sizeof(LocalJob) * jobs.size());
-            LPRT_HIP(hipMemcpyAsync(d_local_jobs.ptr, jobs.data(), sizeof(LocalJob) * jobs.size(), hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL(k_local_levels, dim3((uint32_t)jobs.size()), dim3(256), 0, st, d_vals[cur].as<uint32_t>(), d_tri_bounds.as<float>(),
+        if (plan_jobs)
+            hipLaunchKernelGGL(k_local_levels, dim3(plan_jobs), dim3(256), 0, st, d_vals[cur].as<uint32_t>(), d_tri_bounds.as<float>(),
                                d_blas.as<BlasInfo>(), d_local_jobs.as<LocalJob>());
-            LPRT_HIP(hipStreamSynchronize(st)); // `jobs` is host memory that goes away
-        }
     }
     sorted_buf = cur;
     hipLaunchKernelGGL(k_emit_triangles<T>, dim3(tb), dim3(256), 0, st, d_vals[cur].as<uint32_t>(), d_mf32.as<TriRecF32>(),

@@ -22,6 +22,11 @@ template <typename T> struct GeometryStore {
     // compute_m + ObjectBVH for every primitive, all on the device
     void build_blas(hipStream_t st, bool use_morton = false, bool use_local = true); // LPRT_OPT_BLAS_BUILDER / LPRT_OPT_BLAS_LOCAL
     void radix_sort(hipStream_t st, const std::vector<int> &shifts, int &cur);
+    // the plan of the median build (a function of the triangle counts and of use_local): made once, kept on the device
+    bool plan_valid = false, plan_local = true, plan_dense = false;
+    uint32_t plan_global_levels = 0, plan_jobs = 0;
+    std::vector<uint32_t> plan_level_nodes;
+    void make_plan(hipStream_t st, bool use_local);
 };
 
 template <typename T> struct TlasStore {

@@ -32,10 +32,12 @@ namespace lprt {
     template <typename T> void launch_trace_gi(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t slots, Counters *c);           \
     /* ray streams (stream.hpp): persistent waves that refill finished lanes.  `counter` is a zeroed device word owned by the launch. */           \
     template <typename T>                                                                                                                             \
-    void launch_stream_gi(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t slots, uint32_t *counter, Counters *c, bool wide);  \
+    /* order / n_sorted: the sorted item list of launch_ray_sort_* (null: the stream runs over its items in pixel-block order) */                \
+    void launch_stream_gi(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t slots, uint32_t *counter, Counters *c, bool wide,  \
+                          const uint32_t *order, const uint32_t *n_sorted);                                                                           \
     template <typename T>                                                                                                                             \
     void launch_stream_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, uint32_t slots, uint32_t *counter, Counters *c,  \
-                          bool wide);                                                                                                                 \
+                          bool wide, const uint32_t *order, const uint32_t *n_sorted);                                                                \
     template <typename T>                                                                                                                             \
     void launch_stream_rays(hipStream_t st, const SceneDev<T> &sc, const lprt_ray *rays, uint32_t n, bool any, bool wide, lprt_hit *hits,            \
                             uint32_t *counter, Counters *counters);
@@ -79,6 +81,16 @@ template <typename T> void launch_spp_mean(hipStream_t st, const FrameDev<T> &fb
 // launch_stream_gi leaves a hit record per pixel for launch_shade2 (shade #2 of the hits); launch_stream_di leaves a
 // visibility byte per pixel and light slot for launch_accum_di (accumulate_di_light, and in the last round of a sample
 // write_clean_color) -- together what the fused per-pixel kernels do.
+// Ray sort (pipeline.hip): the stream items that carry a ray, counting-sorted by (cell of the ray's origin on a 32^3 grid over
+// the scene's bounds, Morton order | direction octant) -- `order` (item numbers) and *n_sorted for launch_stream_*.
+// keys: one word per item; bins / offsets: LPRT_RAYSORT_BINS + 4 words each.  which: 0 GI rays, 1 / 2 shadow rays of round 0 / 1
+// (keyed by light slot first: a run of the stream aims at one light).
+#define LPRT_RAYSORT_BINS (1u << 18)
+struct RaySortBufs {
+    uint32_t *keys, *order, *bins, *n_sorted;
+};
+template <typename T> uint32_t ray_sort_items(const FrameDev<T> &fb, uint32_t n_lights, uint32_t slots, int which);
+template <typename T> void launch_ray_sort(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t slots, int which, const RaySortBufs &b);
 template <typename T> void launch_shade2(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t slots);
 template <typename T> void launch_accum_di(hipStream_t st, const FrameDev<T> &fb, bool first, bool gi_on, bool add_direct, uint32_t slots, bool reuse);
 

@@ -803,21 +803,183 @@ template <typename T> struct HostRaySource { // lprt_trace_rays
     }
 };
 
+
+#ifndef LPRT_REFSLAB_TU
+// ---- ray sort: the order a stream hands its rays out in -------------------------------------------------------------------
+// A stream's items are numbered by pixel block, so 64 consecutive GI rays start next to each other but head wherever their
+// BRDF samples sent them, and the shadow rays of round 1 start wherever those GI rays ended.  On the atrium that leaves 6 of
+// 16 lanes active per vector cycle and an L2 hit rate of 0.85 (profiles/r02k_atrium_f16_sq_summary.json): the lanes of a wave
+// walk different parts of a 12-MB hierarchy.  The sort puts the items that carry a ray into the order
+//     key = [light slot (shadow rays)] | Morton code of the origin's cell on a 32^3 grid over the scene's bounds | direction octant
+// by a counting sort over 2^18 bins -- three passes over the items: keys + histogram, scan of the bins, scatter -- with the
+// atomics of a wave aggregated per distinct key (neighbouring pixels share a cell).  The order WITHIN a bin is whatever the
+// scatter's atomics make it; results do not depend on the order at all (every ray reports to its own item), so frames stay
+// bit-identical with the sort on or off (tests).  Items without a ray drop out: the stream is *n_sorted long.
+LPRT_DEV uint32_t spread5(uint32_t v) { // 5 bits -> every third bit
+    v &= 31u;
+    v = (v | (v << 8)) & 0x100fu;
+    v = (v | (v << 4)) & 0x10c3u;
+    v = (v | (v << 2)) & 0x1249u;
+    return v;
+}
+template <typename T> LPRT_DEV uint32_t ray_cell(const SceneDev<T> &sc, V3<T> o) {
+    const float lo[3] = {(float)sc.tlas_root[0], (float)sc.tlas_root[1], (float)sc.tlas_root[2]};
+    const float hi[3] = {(float)sc.tlas_root[3], (float)sc.tlas_root[4], (float)sc.tlas_root[5]};
+    const float p[3] = {(float)o.x, (float)o.y, (float)o.z};
+    uint32_t q[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const float e = hi[k] - lo[k];
+        float f = e > 0.f ? (p[k] - lo[k]) / e * 32.f : 0.f;
+        f = f > 0.f ? f : 0.f; // NaN -> 0
+        q[k] = f < 31.f ? (uint32_t)f : 31u;
+    }
+    return spread5(q[0]) | (spread5(q[1]) << 1) | (spread5(q[2]) << 2);
+}
+template <typename T> LPRT_DEV uint32_t ray_octant(V3<T> d) {
+    return ((float)d.x < 0.f ? 1u : 0u) | ((float)d.y < 0.f ? 2u : 0u) | ((float)d.z < 0.f ? 4u : 0u);
+}
+// the stream item's key (0xffffffff: the item carries no ray); the item numbering is GiSource's / DiSource's
+template <typename T, int WHICH> LPRT_DEV uint32_t ray_sort_key(const SceneDev<T> &sc, const FrameDev<T> &fb0, uint32_t n_slots, uint32_t slots, uint32_t item) {
+    const uint32_t run = item >> 6, l = item & 63u;
+    if (WHICH == 0) {
+        const uint32_t z = run % slots;
+        const FrameDev<T> fb = at_sample(fb0, z);
+        const uint32_t p = block_pixel(fb, run / slots, l);
+        if (p == 0xffffffffu || !fb.gi_valid[p])
+            return 0xffffffffu;
+        return (ray_cell(sc, xyz(fb.g_position[p])) << 3) | ray_octant(xyz(fb.gi_direction[p]));
+    }
+    const uint32_t slot = run % n_slots, r2 = run / n_slots, z = r2 % slots;
+    const FrameDev<T> fb = at_sample(fb0, z);
+    const uint32_t p = block_pixel(fb, r2 / slots, l);
+    if (p == 0xffffffffu || !((fb.lc_mask[p] >> slot) & 1u))
+        return 0xffffffffu;
+    const V3<T> o = xyz(WHICH == 1 ? fb.g_position[p] : fb.sc_position[p]);
+    return (slot << 16) | (ray_cell(sc, o) << 1);
+}
+// one atomic per DISTINCT key of the wave; returns the value before this lane's own contribution (base + rank among equals)
+LPRT_DEV uint32_t wave_bin_add(uint32_t *bins, uint32_t key, bool valid) {
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(valid);
+    uint32_t out = 0;
+    while (todo) {
+        const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
+        const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, (int)leader);
+        const unsigned long long same = __builtin_amdgcn_ballot_w64(valid && key == k);
+        uint32_t base = 0;
+        if (lane == leader)
+            base = atomicAdd(bins + k, (uint32_t)__builtin_popcountll(same));
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
+        if (valid && key == k)
+            out = base + (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    return out;
+}
+template <typename T, int WHICH>
+__global__ void __launch_bounds__(256) k_ray_keys(SceneDev<T> sc, FrameDev<T> fb, uint32_t n_slots, uint32_t slots, uint32_t n_items, uint32_t *keys, uint32_t *bins) {
+    const uint32_t item = blockIdx.x * 256u + threadIdx.x;
+    uint32_t key = 0xffffffffu;
+    if (item < n_items) {
+        key = ray_sort_key<T, WHICH>(sc, fb, n_slots, slots, item);
+        keys[item] = key;
+    }
+    wave_bin_add(bins, key, key != 0xffffffffu);
+}
+// exclusive scan of the bins in place (one workgroup: 2^18 counters are 16 passes of 1024 threads x 16); the total goes to *n_sorted
+__global__ void __launch_bounds__(1024) k_ray_bins_scan(uint32_t *bins, uint32_t n_bins, uint32_t *n_sorted) {
+    __shared__ uint32_t wsum[16];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n_bins; base += 1024u * 16u) {
+        const uint32_t i0 = base + 16u * threadIdx.x;
+        uint32_t v[16];
+#pragma unroll
+        for (int j = 0; j < 16; j += 4) {
+            const uint4 q = *reinterpret_cast<const uint4 *>(bins + i0 + j); // n_bins is a multiple of 16384
+            v[j] = q.x, v[j + 1] = q.y, v[j + 2] = q.z, v[j + 3] = q.w;
+        }
+        uint32_t sum = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t x = v[j];
+            v[j] = sum;
+            sum += x;
+        }
+        uint32_t incl = sum;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off);
+            if (lane >= (uint32_t)off)
+                incl += up;
+        }
+        if (lane == 63u)
+            wsum[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0, tile = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 16u; w++) {
+            const uint32_t x = wsum[w];
+            before += w < wave ? x : 0u;
+            tile += x;
+        }
+        const uint32_t excl = carry + before + incl - sum;
+#pragma unroll
+        for (int j = 0; j < 16; j += 4)
+            *reinterpret_cast<uint4 *>(bins + i0 + j) = make_uint4(excl + v[j], excl + v[j + 1], excl + v[j + 2], excl + v[j + 3]);
+        carry += tile;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        *n_sorted = carry;
+}
+__global__ void __launch_bounds__(256) k_ray_scatter(const uint32_t *keys, uint32_t n_items, uint32_t *bins, uint32_t *order) {
+    const uint32_t item = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t key = item < n_items ? keys[item] : 0xffffffffu;
+    const bool valid = key != 0xffffffffu;
+    const uint32_t pos = wave_bin_add(bins, key, valid);
+    if (valid)
+        order[pos] = item;
+}
+template <typename T> uint32_t ray_sort_items(const FrameDev<T> &fb, uint32_t n_lights, uint32_t slots, int which) {
+    const uint32_t n_slots = std::min<uint32_t>(n_lights, LPRT_MAX_DIRECT_LIGHT);
+    return n_blocks8(fb) * 64u * slots * (which == 0 ? 1u : n_slots);
+}
+template <typename T> void launch_ray_sort(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t slots, int which, const RaySortBufs &b) {
+    const uint32_t n_slots = std::min<uint32_t>(sc.n_lights, LPRT_MAX_DIRECT_LIGHT);
+    const uint32_t n_items = ray_sort_items(fb, sc.n_lights, slots, which);
+    (void)hipMemsetAsync(b.bins, 0, sizeof(uint32_t) * LPRT_RAYSORT_BINS, st);
+    if (!n_items) {
+        (void)hipMemsetAsync(b.n_sorted, 0, sizeof(uint32_t), st);
+        return;
+    }
+    const dim3 g((n_items + 255u) / 256u), blk(256);
+    if (which == 0)
+        hipLaunchKernelGGL((k_ray_keys<T, 0>), g, blk, 0, st, sc, fb, n_slots, slots, n_items, b.keys, b.bins);
+    else if (which == 1)
+        hipLaunchKernelGGL((k_ray_keys<T, 1>), g, blk, 0, st, sc, fb, n_slots, slots, n_items, b.keys, b.bins);
+    else
+        hipLaunchKernelGGL((k_ray_keys<T, 2>), g, blk, 0, st, sc, fb, n_slots, slots, n_items, b.keys, b.bins);
+    hipLaunchKernelGGL(k_ray_bins_scan, dim3(1), dim3(1024), 0, st, b.bins, LPRT_RAYSORT_BINS, b.n_sorted);
+    hipLaunchKernelGGL(k_ray_scatter, g, blk, 0, st, b.keys, n_items, b.bins, b.order);
+}
+#endif // LPRT_REFSLAB_TU
+
 LPRT_VAR_BEGIN
 template <typename T, bool COUNT, bool WIDE>
-__global__ void __launch_bounds__(256, LPRT_STREAM_WAVES) k_stream_gi(SceneDev<T> sc, FrameDev<T> fb, uint32_t slots, uint32_t n_items, uint32_t *counter,
-                                                                       Counters *counters) {
+__global__ void __launch_bounds__(256, LPRT_STREAM_WAVES) k_stream_gi(SceneDev<T> sc, FrameDev<T> fb, uint32_t slots, uint32_t n_items, StreamOrder so,
+                                                                       uint32_t *counter, Counters *counters) {
     Cnt<COUNT> cnt;
     GiSource<T> src{fb, slots};
-    trace_stream<T, false, COUNT, WIDE>(sc, src, n_items, counter, cnt);
+    trace_stream<T, false, COUNT, WIDE>(sc, src, n_items, so, counter, cnt);
     flush_counters<COUNT>(cnt, counters);
 }
 template <typename T, bool FIRST, bool COUNT, bool WIDE>
 __global__ void __launch_bounds__(256, LPRT_STREAM_DI_WAVES) k_stream_di(SceneDev<T> sc, FrameDev<T> fb, uint32_t n_slots, uint32_t slots, uint32_t n_items,
-                                                                       uint32_t *counter, Counters *counters) {
+                                                                       StreamOrder so, uint32_t *counter, Counters *counters) {
     Cnt<COUNT> cnt;
     DiSource<T, FIRST> src{fb, n_slots, slots};
-    trace_stream<T, true, COUNT, WIDE>(sc, src, n_items, counter, cnt);
+    trace_stream<T, true, COUNT, WIDE>(sc, src, n_items, so, counter, cnt);
     flush_counters<COUNT>(cnt, counters);
 }
 template <typename T, bool ANY, bool COUNT, bool WIDE>
@@ -825,7 +987,7 @@ __global__ void __launch_bounds__(256, LPRT_STREAM_WAVES) k_stream_rays(SceneDev
                                                                          Counters *counters) {
     Cnt<COUNT> cnt;
     HostRaySource<T> src{rays, hits};
-    trace_stream<T, ANY, COUNT, WIDE>(sc, src, n, counter, cnt);
+    trace_stream<T, ANY, COUNT, WIDE>(sc, src, n, StreamOrder{nullptr, nullptr}, counter, cnt);
     flush_counters<COUNT>(cnt, counters);
 }
 LPRT_VAR_END
@@ -978,12 +1140,13 @@ template <typename T> void launch_spp_mean(hipStream_t st, const FrameDev<T> &fb
 
 LPRT_VAR_BEGIN
 template <typename T, bool WIDE>
-static void launch_stream_gi_w(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t slots, uint32_t *counter, Counters *c) {
+static void launch_stream_gi_w(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t slots, uint32_t *counter, Counters *c,
+                               const StreamOrder &so) {
     const uint32_t per_slot = n_blocks8(fb) * 64u, n_items = per_slot * slots;
     if (c)
-        hipLaunchKernelGGL((k_stream_gi<T, true, WIDE>), stream_grid(k_stream_gi<T, true, WIDE>, n_items), dim3(256), 0, st, sc, fb, slots, n_items, counter, c);
+        hipLaunchKernelGGL((k_stream_gi<T, true, WIDE>), stream_grid(k_stream_gi<T, true, WIDE>, n_items), dim3(256), 0, st, sc, fb, slots, n_items, so, counter, c);
     else
-        hipLaunchKernelGGL((k_stream_gi<T, false, WIDE>), stream_grid(k_stream_gi<T, false, WIDE>, n_items), dim3(256), 0, st, sc, fb, slots, n_items, counter, c);
+        hipLaunchKernelGGL((k_stream_gi<T, false, WIDE>), stream_grid(k_stream_gi<T, false, WIDE>, n_items), dim3(256), 0, st, sc, fb, slots, n_items, so, counter, c);
 }
 LPRT_VAR_END
 #ifndef LPRT_REFSLAB_TU
@@ -993,37 +1156,42 @@ template <typename T> void launch_shade2(hipStream_t st, const SceneDev<T> &sc, 
 #endif // LPRT_REFSLAB_TU
 LPRT_VAR_BEGIN
 template <typename T>
-void launch_stream_gi(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t slots, uint32_t *counter, Counters *c, bool wide) {
+void launch_stream_gi(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t slots, uint32_t *counter, Counters *c, bool wide,
+                      const uint32_t *order, const uint32_t *n_sorted) {
+    const StreamOrder so{order, n_sorted};
     if (wide)
-        launch_stream_gi_w<T, true>(st, sc, fb, slots, counter, c);
+        launch_stream_gi_w<T, true>(st, sc, fb, slots, counter, c, so);
     else
-        launch_stream_gi_w<T, false>(st, sc, fb, slots, counter, c);
+        launch_stream_gi_w<T, false>(st, sc, fb, slots, counter, c, so);
 }
 template <typename T, bool FIRST, bool WIDE>
-static void launch_stream_di_w(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t slots, uint32_t *counter, Counters *c) {
+static void launch_stream_di_w(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, uint32_t slots, uint32_t *counter, Counters *c,
+                               const StreamOrder &so) {
     const uint32_t n_slots = std::min<uint32_t>(sc.n_lights, LPRT_MAX_DIRECT_LIGHT);
     const uint32_t per_slot = n_blocks8(fb) * 64u * n_slots, n_items = per_slot * slots;
     if (!n_items)
         return;
     if (c)
         hipLaunchKernelGGL((k_stream_di<T, FIRST, true, WIDE>), stream_grid(k_stream_di<T, FIRST, true, WIDE>, n_items), dim3(256), 0, st, sc, fb, n_slots,
-                           slots, n_items, counter, c);
+                           slots, n_items, so, counter, c);
     else
         hipLaunchKernelGGL((k_stream_di<T, FIRST, false, WIDE>), stream_grid(k_stream_di<T, FIRST, false, WIDE>, n_items), dim3(256), 0, st, sc, fb, n_slots,
-                           slots, n_items, counter, c);
+                           slots, n_items, so, counter, c);
 }
 template <typename T>
-void launch_stream_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, uint32_t slots, uint32_t *counter, Counters *c, bool wide) {
+void launch_stream_di(hipStream_t st, const SceneDev<T> &sc, const FrameDev<T> &fb, bool first, uint32_t slots, uint32_t *counter, Counters *c, bool wide,
+                      const uint32_t *order, const uint32_t *n_sorted) {
+    const StreamOrder so{order, n_sorted};
     if (first) {
         if (wide)
-            launch_stream_di_w<T, true, true>(st, sc, fb, slots, counter, c);
+            launch_stream_di_w<T, true, true>(st, sc, fb, slots, counter, c, so);
         else
-            launch_stream_di_w<T, true, false>(st, sc, fb, slots, counter, c);
+            launch_stream_di_w<T, true, false>(st, sc, fb, slots, counter, c, so);
     } else {
         if (wide)
-            launch_stream_di_w<T, false, true>(st, sc, fb, slots, counter, c);
+            launch_stream_di_w<T, false, true>(st, sc, fb, slots, counter, c, so);
         else
-            launch_stream_di_w<T, false, false>(st, sc, fb, slots, counter, c);
+            launch_stream_di_w<T, false, false>(st, sc, fb, slots, counter, c, so);
     }
 }
 LPRT_VAR_END
@@ -1064,8 +1232,10 @@ void launch_stream_rays(hipStream_t st, const SceneDev<T> &sc, const lprt_ray *r
 }
 
 #define INST_TRACE(T)                                                                                                  \
-    template void launch_stream_gi<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, uint32_t, uint32_t *, Counters *, bool); \
-    template void launch_stream_di<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, uint32_t, uint32_t *, Counters *, bool); \
+    template void launch_stream_gi<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, uint32_t, uint32_t *, Counters *, bool, const uint32_t *, \
+                                      const uint32_t *);                                                                \
+    template void launch_stream_di<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, uint32_t, uint32_t *, Counters *, bool,     \
+                                      const uint32_t *, const uint32_t *);                                             \
     template void launch_stream_rays<T>(hipStream_t, const SceneDev<T> &, const lprt_ray *, uint32_t, bool, bool, lprt_hit *, uint32_t *, Counters *); \
     template void launch_fill_gbuffer<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, Counters *);          \
     template void launch_trace_di<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, bool, bool, uint32_t, bool, Counters *, bool); \
@@ -1080,6 +1250,8 @@ LPRT_VAR_END
 #ifndef LPRT_REFSLAB_TU
 #define INST(T)                                                                                                        \
     template void launch_shade2<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, uint32_t);                   \
+    template uint32_t ray_sort_items<T>(const FrameDev<T> &, uint32_t, uint32_t, int);                                 \
+    template void launch_ray_sort<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, uint32_t, int, const RaySortBufs &); \
     template void launch_accum_di<T>(hipStream_t, const FrameDev<T> &, bool, bool, bool, uint32_t, bool);              \
     template void launch_spp_mean<T>(hipStream_t, const FrameDev<T> &, uint32_t, uint32_t, uint32_t);                  \
     template void launch_temporal_map<T>(hipStream_t, const SceneDev<T> &, const FrameDev<T> &, bool, uint32_t, bool);      \

@@ -66,8 +66,17 @@ template <typename T> struct WorldRay { // 60 B (f32) / 48 B (f16) per lane
 #endif
 
 // Src: load(item, ray, tmin, tmax, skip_vao, skip_off) -> bool (false: the item carries no ray), store(item, Isect).
+// Ray order (pipeline.hip "ray sort"): with `order` the stream's j-th work item is order[j] instead of j -- the items that carry
+// a ray, counting-sorted by (cell of the ray's origin, direction octant) -- and the stream is *n_sorted long: 64 consecutive
+// items are then rays that start in one cell and head the same way, whatever pixels they belong to, and an XCD's range of
+// the stream is one region of the scene.  Results do not depend on the order (a ray's record goes to its own item).
+struct StreamOrder {
+    const uint32_t *order;    // null: identity
+    const uint32_t *n_sorted; // device word: items in `order`
+};
 template <typename T, bool ANY, bool COUNT, bool WIDE, typename Src>
-LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items, uint32_t *stream_counter, Cnt<COUNT> &cnt) {
+LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items_all, const StreamOrder &so, uint32_t *stream_counter, Cnt<COUNT> &cnt) {
+    const uint32_t n_items = so.order ? *so.n_sorted : n_items_all;
     __shared__ PrepRay<T> s_ring[4][LPRT_STREAM_RING];
     __shared__ WorldRay<T> s_world[256];
     PrepRay<T> *ring = s_ring[threadIdx.x >> 6];
@@ -125,8 +134,9 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items, ui
                 exhausted = true;
             PrepRay<T> pr;
             RayT<T> nray{zero3<T>(), zero3<T>()};
-            pr.item = base + lane;
-            const bool ok = pr.item < limit && src.load(pr.item, nray, pr.tmin, pr.tmax, pr.skip_vao, pr.skip_off);
+            const uint32_t j = base + lane;
+            pr.item = (so.order && j < limit) ? so.order[j] : j;
+            const bool ok = j < limit && src.load(pr.item, nray, pr.tmin, pr.tmax, pr.skip_vao, pr.skip_off);
             if (ok) {
                 if (COUNT)
                     cnt.rays++;
@@ -157,6 +167,9 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items, ui
             if (ok)
                 ring[(head + (uint32_t)__builtin_popcountll(okm & lt_mask)) & (LPRT_STREAM_RING - 1u)] = pr;
             head += (uint32_t)__builtin_popcountll(okm);
+            // the ring is written by some lanes and read by others of the SAME wave: a wave barrier (no instruction, a
+            // scheduling fence) keeps the compiler from moving the hand-out's LDS reads above these writes
+            __builtin_amdgcn_wave_barrier();
         }
         // ---- hand out: idle lanes take parked rays ----------------------------------------------------------------------
         {
@@ -190,6 +203,7 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items, ui
                     is.bary = zero3<T>();
                 }
                 tail += n_take;
+                __builtin_amdgcn_wave_barrier(); // ring slots read above may be overwritten by the next prepare
             }
         }
         if (!__builtin_amdgcn_ballot_w64(has_ray)) {

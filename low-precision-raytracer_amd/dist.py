@@ -73,7 +73,7 @@ class ShardedFrame:
     rehearsal) stages through host memory.
     """
 
-    def __init__(self, width, height, rank, world_size, device, backend="nccl", halo=HALO_ROWS, trace_halo=True):
+    def __init__(self, width, height, rank, world_size, device, backend="nccl", halo=HALO_ROWS, trace_halo=True, defer_gather=False):
         import torch
         self.trace_halo = trace_halo or world_size == 1
         self.torch = torch
@@ -90,6 +90,18 @@ class ShardedFrame:
         self.send = torch.zeros((rows, width, 4), dtype=torch.float32, device=device)
         if not self.equal:
             self.recv = torch.zeros((world_size, self.max_rows, width, 4), dtype=torch.float32, device=device)
+        # Deferred all-gather (opt-in; equal strips only): the gather of frame n is started asynchronously and runs under
+        # frame n + 1 -- the renderer writes frame n + 1's rows into the OTHER of two strip buffers, the gathered image
+        # alternates likewise -- and is waited for when frame n + 1's gather is posted.  all_gather() then returns the image
+        # of the PREVIOUS frame (None after the first); flush() waits for and returns the newest.  Frames come out in
+        # order, one call later (tests/test_dist_gloo.py).
+        self.defer = bool(defer_gather) and world_size > 1 and self.equal
+        self.bytes_gathered = 0  # bytes this rank contributed to all-gathers so far
+        self.gathers = 0
+        if self.defer:
+            self._sends = [self.send, torch.zeros_like(self.send)]
+            self._images = [self.image, torch.zeros_like(self.image)]
+            self._slot, self._pending, self._renderer = 0, None, None
 
     def target(self):
         """(device pointer, first_row, n_rows) for lprt_set_output_target."""
@@ -100,6 +112,10 @@ class ShardedFrame:
         torch = self.torch
         if self.world == 1:
             return self.send  # one GPU: the strip is the frame
+        self.bytes_gathered += self.send.numel() * self.send.element_size()
+        self.gathers += 1
+        if self.defer:
+            return self._all_gather_deferred()
         staged = self.backend != "nccl" and self.send.is_cuda
         if self.equal:
             if staged:
@@ -120,10 +136,41 @@ class ShardedFrame:
                 self.image[b:e].copy_(self.recv[r, :e - b])
         return self.image
 
+    def _all_gather_deferred(self):
+        import torch.distributed as dist
+        prev = self.flush()  # at most one gather in flight: frame n - 1's has had all of frame n to finish
+        send, image = self._sends[self._slot], self._images[self._slot]
+        if self.backend != "nccl" and send.is_cuda:  # rehearsal through host memory
+            host_in, host_out = send.cpu(), self.torch.empty(image.shape, dtype=self.torch.float32)
+            work = dist.all_gather_into_tensor(host_out.view(-1), host_in.view(-1), async_op=True)
+            self._pending = (work, image, host_out)
+        else:
+            work = dist.all_gather_into_tensor(image.view(-1), send.view(-1), async_op=True)
+            self._pending = (work, image, None)
+        # the next frame's rows go to the other strip buffer while this one is being read by the transport
+        self._slot ^= 1
+        self.send, self.image = self._sends[self._slot], self._images[self._slot]
+        if self._renderer is not None:
+            ptr, first_row, n_rows = self.target()
+            self._renderer.set_output_target(ptr, first_row, n_rows)
+        return prev
+
+    def flush(self):
+        """Deferred mode: wait for the gather in flight and return its image (None if there is none)."""
+        if not getattr(self, "defer", False) or self._pending is None:
+            return None
+        work, image, host_out = self._pending
+        self._pending = None
+        work.wait()
+        if host_out is not None:
+            image.copy_(host_out)
+        return image
 
     def attach(self, renderer):
         """Output target + the rows the per-sample stages run on (the strip alone unless the halo is traced locally)."""
         ptr, first_row, n_rows = self.target()
+        if getattr(self, "defer", False):
+            self._renderer = renderer
         renderer.set_output_target(ptr, first_row, n_rows)
         if not self.trace_halo:
             renderer.set_sample_rows(self.begin, self.end - self.begin)

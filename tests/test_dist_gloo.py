@@ -57,6 +57,70 @@ def _run(H, W, world=2):
         assert abs(tmax - 0.1 * world) < 1e-12
 
 
+def _deferred_worker(rank, world, port, H, W, q):
+    """The deferred all-gather (ShardedFrame(defer_gather=True)): frame n's gather runs under frame n + 1.  Six frames with
+    distinct contents: all_gather() returns frame n - 1, flush() the last one -- every frame, in order, complete on every
+    rank, bit-equal to what the immediate gather assembles."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    tdist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class Target:  # stands in for lprt_set_output_target: where the renderer would write this rank's rows
+        def set_output_target(self, ptr, first_row, n_rows):
+            self.ptr = ptr
+
+    def strip_of(frame, k):
+        b, e = frame.begin, frame.end
+        rows = torch.arange(b, e, dtype=torch.float32).view(-1, 1, 1)
+        cols = torch.arange(W, dtype=torch.float32).view(1, -1, 1)
+        ch = torch.arange(4, dtype=torch.float32).view(1, 1, -1)
+        return rows * 1000 + cols * 4 + ch + 100000 * k
+
+    got = {}
+    for defer in (False, True):
+        frame = dist.ShardedFrame(W, H, rank, world, torch.device("cpu"), backend="gloo", defer_gather=defer)
+        tgt = Target()
+        frame.attach(tgt)
+        imgs = []
+        for k in range(6):
+            assert tgt.ptr == frame.send.data_ptr()  # the renderer's target is the buffer the NEXT gather will read
+            frame.send[:frame.end - frame.begin] = strip_of(frame, k)
+            out = frame.all_gather()
+            if not defer:
+                imgs.append(out.numpy().copy())
+            elif k == 0:
+                assert out is None
+            else:
+                imgs.append(out.numpy().copy())
+        if defer:
+            imgs.append(frame.flush().numpy().copy())
+            assert frame.flush() is None
+        got[defer] = imgs
+        assert frame.gathers == 6 and frame.bytes_gathered == 6 * frame.send.numel() * 4
+    ok = len(got[True]) == 6 and all(np.array_equal(a, b) for a, b in zip(got[False], got[True]))
+    want0 = (np.arange(H, dtype=np.float32).reshape(-1, 1, 1) * 1000 + np.arange(W, dtype=np.float32).reshape(1, -1, 1) * 4 +
+             np.arange(4, dtype=np.float32).reshape(1, 1, -1))
+    ok = ok and all(np.array_equal(img, want0 + 100000 * k) for k, img in enumerate(got[True]))
+    q.put((rank, ok))
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+def test_deferred_all_gather_returns_the_same_frames_in_order():
+    for world in (2, 4):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_deferred_worker, args=(r, world, port, 16, 5, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=120) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert all(ok for _, ok in res), res
+
+
 def test_all_gather_equal_strips():
     _run(H=16, W=5)
 
