@@ -229,7 +229,8 @@ typedef enum {
     LPRT_STAGE_SVGF_WAVELET = 14,  /* k_wavelet<1,2,4,8,16>: five launches per frame */
     LPRT_STAGE_FINALIZE = 15,      /* k_finalize                add_denoised_color + "TAA" + output + pixel ids */
     LPRT_STAGE_BACKUP = 16,        /* k_copy_last_transform     "Backup Temporal Data" */
-    LPRT_STAGE_COUNT = 17
+    LPRT_STAGE_RAY_SORT = 17,      /* k_ray_keys + k_ray_bins_scan + k_ray_scatter in front of a ray stream (LPRT_OPT_RAY_SORT) */
+    LPRT_STAGE_COUNT = 18
 } lprt_stage_id;
 
 typedef struct lprt_ctx lprt_ctx;
@@ -450,7 +451,14 @@ typedef enum {
                                      * differ".  Unlike every other option this one CHANGES half-precision results (which boxes a ray
                                      * is admitted to); single precision is unaffected (its default arithmetic is the reference's).
                                      * LPRT_REFERENCE_SLAB */
-    LPRT_OPT_COUNT = 16
+    LPRT_OPT_RAY_SORT = 16,         /* the order a ray stream hands its rays out in (csrc/pipeline.hip "ray sort"): the stream items that
+                                     * carry a ray, counting-sorted on the device by (light slot for shadow rays, Morton code of the
+                                     * origin's cell on a 32^3 grid over the scene, direction octant), so that the 64 rays of a batch
+                                     * start in one cell and head the same way.  Bit 0: GI rays, bit 1: shadow rays that run as a stream;
+                                     * 0 / -1 (default): pixel-block order -- measured on the atrium the sorted order buys 0 % (GI rays) and
+                                     * 11 % (round-1 shadow rays) of the traversal time and the sort costs several times that
+                                     * (DESIGN.md 4.1).  Results never depend on it.  LPRT_RAY_SORT */
+    LPRT_OPT_COUNT = 17
 } lprt_option;
 int lprt_set_option(lprt_ctx *ctx, lprt_option option, int value);
 int lprt_get_option(lprt_ctx *ctx, lprt_option option, int *value);

@@ -85,7 +85,7 @@ BUF_CHANNELS = {0: 3, 1: 3, 2: 3, 3: 3, 4: 3, 5: 3, 6: 4, 7: 4, 8: 4, 9: 4, 10: 
                 16: 3, 17: 4, 18: 4, 19: 1, 20: 3, 21: 2}
 BUF_PLANES = {18: MAX_DIRECT_LIGHT}  # leading dimension of buffers that are [planes][rows][W][channels]
 STAGES = ["build_blas", "build_tlas", "primary", "temporal_map", "rng", "shade1", "trace_di1", "trace_gi", "shade2",
-          "trace_di2", "compose", "svgf_gradient", "svgf_temporal", "svgf_moments", "svgf_wavelet", "finalize", "backup"]
+          "trace_di2", "compose", "svgf_gradient", "svgf_temporal", "svgf_moments", "svgf_wavelet", "finalize", "backup", "ray_sort"]
 # device kernel behind each stage id (the names rocprofv3 --kernel-trace reports)
 STAGE_KERNELS = {"primary": "k_fill_gbuffer", "temporal_map": "k_temporal_map", "rng": "k_rng_expand", "shade1": "k_shade",
                  "trace_di1": "k_trace_di", "trace_gi": "k_trace_gi", "shade2": "k_shade2", "trace_di2": "k_trace_di",
@@ -96,7 +96,7 @@ STAGE_KERNELS = {"primary": "k_fill_gbuffer", "temporal_map": "k_temporal_map", 
 # lprt_option, in enum order
 OPTIONS = ["wide_walk", "tlas_mode", "axis_reject", "svgf_always_test", "blas_builder", "blas_local", "debug_sync", "ray_stream",
            "stream_wide_closest", "stream_refill_min", "stream_node_min", "stream_sched", "sample_batch",
-           "floor_reprojection", "stream_xcd", "reference_slab"]
+           "floor_reprojection", "stream_xcd", "reference_slab", "ray_sort"]
 RNG_STATE_WORDS = 6
 
 

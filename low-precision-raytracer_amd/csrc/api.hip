@@ -91,7 +91,7 @@ struct CtxBase {
     uint32_t sample_first = 0, sample_rows = 0; // 0 rows: the whole window
     int next_phase = LPRT_PHASE_SAMPLE;
     // behaviour knobs (lprt_option): initialised from the environment once, in lprt_create; never read from it afterwards
-    int opts[LPRT_OPT_COUNT] = {-1, -1, 1, 0, 0, 1, 0, -1, 0, 12, 20, 0, (int)LPRT_MAX_SAMPLE_BATCH, 0, 1, 0};
+    int opts[LPRT_OPT_COUNT] = {-1, -1, 1, 0, 0, 1, 0, -1, 0, 12, 20, 0, (int)LPRT_MAX_SAMPLE_BATCH, 0, 1, 0, -1};
     bool reference_slab() const { return opts[LPRT_OPT_REFERENCE_SLAB] != 0; }
     void options_from_environment() {
         if (const char *w = std::getenv("LPRT_WIDE_WALK"))
@@ -118,6 +118,8 @@ struct CtxBase {
             opts[LPRT_OPT_STREAM_XCD] = r[0] == '0' ? 0 : 1;
         if (const char *r = std::getenv("LPRT_STREAM_SCHED"))
             opts[LPRT_OPT_STREAM_SCHED] = r[0] == '1' ? 1 : 0;
+        if (const char *r = std::getenv("LPRT_RAY_SORT"))
+            opts[LPRT_OPT_RAY_SORT] = std::max(0, std::min(3, std::atoi(r)));
         if (const char *r = std::getenv("LPRT_REFERENCE_SLAB"))
             opts[LPRT_OPT_REFERENCE_SLAB] = r[0] == '1' ? 1 : 0;
         if (const char *r = std::getenv("LPRT_STREAM_WIDE_CLOSEST"))
@@ -423,6 +425,28 @@ template <typename T> struct Impl : CtxBase {
     uint32_t stream_launches = 0;
     uint32_t *next_stream_counter() { return d_stream_counters.as<uint32_t>() + LPRT_STREAM_COUNTER_WORDS * (size_t)stream_launches++; }
     bool wide_anyhit() const { return opts[LPRT_OPT_WIDE_WALK] < 0 ? geo.max_depth >= 6 : opts[LPRT_OPT_WIDE_WALK] != 0; }
+    // ray sort (pipeline.hip): the items of a ray stream in (origin cell, direction octant) order.  Bit 0 of the option: GI rays,
+    // bit 1: the shadow rays of round 1 (and of round 0 when they run as a stream); -1: both
+    int ray_sort() const { return opts[LPRT_OPT_RAY_SORT] < 0 ? 0 : opts[LPRT_OPT_RAY_SORT]; } // measured: costs more than it buys (pipeline.hip)
+    DevBuf d_sort_keys, d_sort_order, d_sort_bins;
+    // sorts the items of the stream about to be launched (which: 0 GI, 1 / 2 shadow rays of round 0 / 1); null order: not sorted
+    RaySortBufs sort_stream(const SceneDev<T> &sc, const FrameDev<T> &sv, uint32_t slots, int which) {
+        RaySortBufs b{nullptr, nullptr, nullptr, nullptr};
+        if (!((ray_sort() >> (which == 0 ? 0 : 1)) & 1))
+            return b;
+        const uint32_t n_items = ray_sort_items<T>(sv, sc.n_lights, slots, which);
+        if (!n_items)
+            return b;
+        // sized for the largest stream of the batch at once (the shadow rays: items x light slots): growing later would free a
+        // buffer the previous stream may still be reading
+        const size_t n_max = std::max<size_t>(n_items, ray_sort_items<T>(sv, sc.n_lights, slots, 2));
+        d_sort_keys.reserve(sizeof(uint32_t) * n_max);
+        d_sort_order.reserve(sizeof(uint32_t) * n_max);
+        d_sort_bins.reserve(sizeof(uint32_t) * (LPRT_RAYSORT_BINS + 4u));
+        b = RaySortBufs{d_sort_keys.as<uint32_t>(), d_sort_order.as<uint32_t>(), d_sort_bins.as<uint32_t>(), d_sort_bins.as<uint32_t>() + LPRT_RAYSORT_BINS};
+        launch_ray_sort<T>(stream, sc, sv, slots, which, b);
+        return b;
+    }
     uint32_t jitter_d = 0; // d word of this frame's seed A, drawn in the sample phase, used by the temporal maps
     void render_phase(const lprt_frame_settings &fs, int phase) override {
         if (phase != next_phase)
@@ -508,10 +532,15 @@ template <typename T> struct Impl : CtxBase {
             stage(LPRT_STAGE_SHADE1, [&] { launch_shade<T>(stream, sc, sv, !fs.gi_on, sb); });
             // round 0's shadow rays: every slot, or (reuse) slot 0 of the batch that holds sample 0
             const uint32_t n_round0 = !reuse ? n : (s0 == 0 ? 1u : 0u);
+            RaySortBufs sorted[3] = {};
+            if (n_round0 && stream_round0)
+                stage(LPRT_STAGE_RAY_SORT, [&] { sorted[1] = sort_stream(sc, sv, n_round0, 1); });
             if (n_round0)
                 stage(LPRT_STAGE_TRACE_DI1, [&] {
                     if (stream_round0) {
-                        LPRT_TRACE(launch_stream_di)(stream, sc, sv, true, n_round0, next_stream_counter(), stage_counters(LPRT_STAGE_TRACE_DI1), wide_walk);
+                        const RaySortBufs so = sorted[1];
+                        LPRT_TRACE(launch_stream_di)(stream, sc, sv, true, n_round0, next_stream_counter(), stage_counters(LPRT_STAGE_TRACE_DI1), wide_walk,
+                                                     so.order, so.n_sorted);
                         launch_accum_di<T>(stream, sv, true, fs.gi_on != 0, fs.add_direct_out != 0, n_round0, reuse);
                     } else
                         LPRT_TRACE(launch_trace_di)(stream, sc, sv, true, fs.gi_on != 0, fs.add_direct_out != 0, n_round0, reuse,
@@ -521,12 +550,18 @@ template <typename T> struct Impl : CtxBase {
                 // trace_gi + shade #2 of the hit in one kernel; trace_di #2 + write_clean_color in the next
                 // (ray streams: each of the two as a traversal kernel + a per-pixel kernel, timed as stages of their own)
                 if (streams) {
+                    stage(LPRT_STAGE_RAY_SORT, [&] { sorted[0] = sort_stream(sc, sv, n, 0); });
                     stage(LPRT_STAGE_TRACE_GI, [&] {
-                        LPRT_TRACE(launch_stream_gi)(stream, sc, sv, n, next_stream_counter(), stage_counters(LPRT_STAGE_TRACE_GI), wide_closest);
+                        const RaySortBufs so = sorted[0];
+                        LPRT_TRACE(launch_stream_gi)(stream, sc, sv, n, next_stream_counter(), stage_counters(LPRT_STAGE_TRACE_GI), wide_closest, so.order,
+                                                     so.n_sorted);
                     });
                     stage(LPRT_STAGE_SHADE2, [&] { launch_shade2<T>(stream, sc, sv, n); });
+                    stage(LPRT_STAGE_RAY_SORT, [&] { sorted[2] = sort_stream(sc, sv, n, 2); });
                     stage(LPRT_STAGE_TRACE_DI2, [&] {
-                        LPRT_TRACE(launch_stream_di)(stream, sc, sv, false, n, next_stream_counter(), stage_counters(LPRT_STAGE_TRACE_DI2), wide_walk);
+                        const RaySortBufs so = sorted[2];
+                        LPRT_TRACE(launch_stream_di)(stream, sc, sv, false, n, next_stream_counter(), stage_counters(LPRT_STAGE_TRACE_DI2), wide_walk,
+                                                     so.order, so.n_sorted);
                     });
                     stage(LPRT_STAGE_COMPOSE, [&] { launch_accum_di<T>(stream, sv, false, true, fs.add_direct_out != 0, n, reuse); });
                 } else {
@@ -1273,6 +1308,12 @@ int lprt_set_option(lprt_ctx *ctx, lprt_option option, int value) {
         if ((int)option < 0 || (int)option >= LPRT_OPT_COUNT)
             throw std::string("unknown option");
         const bool tri = option == LPRT_OPT_WIDE_WALK || option == LPRT_OPT_TLAS_MODE || option == LPRT_OPT_RAY_STREAM; // -1 = automatic
+        if (option == LPRT_OPT_RAY_SORT) { // a bit set
+            if (value < -1 || value > 3)
+                throw std::string("option value out of range");
+            c.opts[option] = value;
+            return;
+        }
         const bool lanes = option == LPRT_OPT_STREAM_REFILL_MIN || option == LPRT_OPT_STREAM_NODE_MIN;       // a lane count
         if (option == LPRT_OPT_SAMPLE_BATCH ? (value < 1 || value > (int)LPRT_MAX_SAMPLE_BATCH)
                                             : lanes ? (value < 1 || value > 64) : (value > 1 || value < (tri ? -1 : 0)))

@@ -812,9 +812,15 @@ template <typename T> struct HostRaySource { // lprt_trace_rays
 // walk different parts of a 12-MB hierarchy.  The sort puts the items that carry a ray into the order
 //     key = [light slot (shadow rays)] | Morton code of the origin's cell on a 32^3 grid over the scene's bounds | direction octant
 // by a counting sort over 2^18 bins -- three passes over the items: keys + histogram, scan of the bins, scatter -- with the
-// atomics of a wave aggregated per distinct key (neighbouring pixels share a cell).  The order WITHIN a bin is whatever the
-// scatter's atomics make it; results do not depend on the order at all (every ray reports to its own item), so frames stay
-// bit-identical with the sort on or off (tests).  Items without a ray drop out: the stream is *n_sorted long.
+// atomics of a wave aggregated per distinct key.  The order WITHIN a bin is whatever the scatter's atomics make it; results do
+// not depend on the order at all (every ray reports to its own item), so frames stay bit-identical with the sort on or off
+// (tests/test_gpu_frame.py::test_launch_structure_never_changes_a_frame).  Items without a ray drop out: the stream is
+// *n_sorted long.
+// MEASURED (round 3, MI355X, atrium 1080p 8 spp fp16, gpurun_out/ab_sort_*.json): GI rays 7.93 -> 7.86 ms per frame -- nothing:
+// their origins were already neighbours (8x8 pixel blocks) and an octant is half of the hemisphere they are drawn from;
+// shadow rays of round 1 7.42 -> 6.61 ms (-11 %: these start wherever the GI rays ended).  The sort itself costs 1.6 / 4.9 ms
+// per frame in this form (device-scope atomics), several times what it buys, so LPRT_OPT_RAY_SORT defaults to OFF; a sort
+// worth having here would have to cost < 0.5 ms per 50 M items (LDS-privatised radix passes) for a net gain of ~2 %.
 LPRT_DEV uint32_t spread5(uint32_t v) { // 5 bits -> every third bit
     v &= 31u;
     v = (v | (v << 8)) & 0x100fu;
@@ -858,7 +864,9 @@ template <typename T, int WHICH> LPRT_DEV uint32_t ray_sort_key(const SceneDev<T
     const V3<T> o = xyz(WHICH == 1 ? fb.g_position[p] : fb.sc_position[p]);
     return (slot << 16) | (ray_cell(sc, o) << 1);
 }
-// one atomic per DISTINCT key of the wave; returns the value before this lane's own contribution (base + rank among equals)
+// one atomic per DISTINCT key of the wave; returns the value before this lane's own contribution (base + rank among equals).
+// (One plain atomic per lane measured far slower: GI rays 7.8 ms instead of 1.6 ms per frame -- neighbouring pixels hit the same
+// bin, and device-scope atomics on one address serialise.)
 LPRT_DEV uint32_t wave_bin_add(uint32_t *bins, uint32_t key, bool valid) {
     const uint32_t lane = threadIdx.x & 63u;
     unsigned long long todo = __builtin_amdgcn_ballot_w64(valid);

@@ -208,19 +208,20 @@ def test_launch_structure_never_changes_a_frame(scene_name, W, H, prec):
     input -- for every combination, and so do the ray counts."""
     sc = scenes.SCENES[scene_name]()
     outs = {}
-    for stream, batch, xcd in ((0, 1, 1), (0, 8, 1), (1, 1, 1), (1, 2, 0), (1, 8, 1), (1, 8, 0), (-1, 8, 1)):
+    for stream, batch, xcd, sort in ((0, 1, 1, 0), (0, 8, 1, 3), (1, 1, 1, 0), (1, 2, 0, 1), (1, 8, 1, 0), (1, 8, 0, 2), (1, 8, 1, 3), (-1, 8, 1, -1)):
         with lprt_amd.Renderer(W, H, prec) as r:
             r.set_option("ray_stream", stream)
             r.set_option("sample_batch", batch)
             r.set_option("stream_xcd", xcd)  # one work counter, or eight item ranges drained XCD group by XCD group
+            r.set_option("ray_sort", sort)   # stream items in pixel-block order, or sorted by (origin cell, direction octant)
             r.load_scene(sc)
             r.enable_counters(True)
             for _ in range(3):
                 r.set_scene(sc)
                 r.render(abi.default_settings(spp=3))
-            outs[(stream, batch, xcd)] = [r.read(n) for n in ("OUTPUT", "INTENSITY0", "INTENSITY1", "RAW_GI_COLORED", "RAW_COLOR", "GI_DIRECTION")] + \
+            outs[(stream, batch, xcd, sort)] = [r.read(n) for n in ("OUTPUT", "INTENSITY0", "INTENSITY1", "RAW_GI_COLORED", "RAW_COLOR", "GI_DIRECTION")] + \
                                     [np.array([r.stage_counters(st)["rays"] for st in ("primary", "trace_di1", "trace_gi", "trace_di2")])]
-    first = outs[(0, 1, 1)]
+    first = outs[(0, 1, 1, 0)]
     for key, got in outs.items():
         for a, b in zip(first, got):
             assert np.array_equal(a, b, equal_nan=True), key
@@ -673,7 +674,7 @@ def test_render_phases_and_sample_rows_are_checked(cornell):
 def test_options_out_array_sizes_and_null_pointers_are_checked(cornell):
     import ctypes as C
     with lprt_amd.Renderer(32, 32, abi.F32) as r:
-        assert [r.get_option(n) for n in abi.OPTIONS] == [-1, -1, 1, 0, 0, 1, 0, -1, 0, 12, 20, 0, 8, 0, 1, 0]
+        assert [r.get_option(n) for n in abi.OPTIONS] == [-1, -1, 1, 0, 0, 1, 0, -1, 0, 12, 20, 0, 8, 0, 1, 0, -1]
         r.set_option("wide_walk", 1)
         assert r.get_option("wide_walk") == 1
         with pytest.raises(lprt_amd.LprtError, match="out of range"):
