@@ -368,12 +368,15 @@ int lprt_set_stage_timing_mask(lprt_ctx *ctx, uint32_t stage_mask);
 int lprt_get_stage_times(lprt_ctx *ctx, float *ms, uint32_t *launches, uint32_t n);
 int lprt_reset_stage_times(lprt_ctx *ctx);
 
-/* Acceleration-structure read-back for parity tests against the oracle's traversal:
- * sizes first (nodes == NULL), then data. Layout documented in DESIGN.md. */
+/* Acceleration-structure read-back (tests): n_nodes = 2^depth - 1 heap slots of node records (children of slot i at 2i,
+ * 2i + 1); tri_order = the primitive's triangles in leaf order; per slot both child boxes (boxes12 =
+ * [n_nodes][2][lo xyz, hi xyz]) and both leaf words ([n_nodes][2]: 0xffffffff = the child is an inner node with a record of
+ * its own, else (first << 3) | count of the triangles the child holds as a leaf, in leaf order).  Slots the builder did not
+ * reach hold unspecified data: walk the tree from slot 1. */
 int lprt_get_blas_info(lprt_ctx *ctx, uint32_t vao_index, uint32_t *n_triangles, uint32_t *n_nodes,
                        uint32_t *depth);
 int lprt_read_blas_order(lprt_ctx *ctx, uint32_t vao_index, uint32_t *tri_order, uint32_t n);
-int lprt_read_blas_boxes(lprt_ctx *ctx, uint32_t vao_index, float *boxes6, uint32_t n_nodes);
+int lprt_read_blas_nodes(lprt_ctx *ctx, uint32_t vao_index, float *root6, float *boxes12, uint32_t *leaf_words2, uint32_t n_nodes);
 
 /* Test hook: the texture fetch shade() makes (normalised coordinates, wrap, bilinear with 1.8 fixed-point weights,
  * optional sRGB decode) at uv[n][2]; rgba = [n][4] floats. */
@@ -408,7 +411,12 @@ typedef enum {
                                     * slab test.  LPRT_NO_AXIS_REJECT (set = 0) */
     LPRT_OPT_SVGF_ALWAYS_TEST = 3, /* 0 (default); 1: SVGF window sums always take the per-sample finite tests.
                                     * LPRT_SVGF_ALWAYS_TEST (set = 1) */
-    LPRT_OPT_BLAS_BUILDER = 4,     /* 0 (default): level-by-level median split; 1: one Morton sort.  LPRT_BLAS_BUILDER=morton */
+    LPRT_OPT_BLAS_BUILDER = 4,     /* -1 (default): the surface-area builder when some primitive has >= 64 triangles, else the median
+                                    * split; 0: level-by-level median split (the reference's rule, object_bvh.hpp:76-134); 1: one
+                                    * Morton sort; 2: binned surface-area heuristic, depth-bounded, leaves of <= 2 triangles at any
+                                    * depth (csrc/build.hip: k_sah_level).  Hit records never depend on it except at exact-t ties
+                                    *  and, in half precision, where box culling depends on the tree.
+                                    * LPRT_BLAS_BUILDER=median|morton|sah */
     LPRT_OPT_BLAS_LOCAL = 5,       /* 1 (default): subtrees of <= 1024 triangles are ordered in LDS; 0: global passes only.
                                     * LPRT_BLAS_LOCAL */
     LPRT_OPT_DEBUG_SYNC = 6,       /* 1: synchronise and report after every stage.  LPRT_DEBUG_SYNC (set = 1) */

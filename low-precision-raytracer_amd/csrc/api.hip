@@ -80,7 +80,7 @@ struct CtxBase {
     virtual void reset_counters() = 0;
     virtual void blas_info(uint32_t, uint32_t *, uint32_t *, uint32_t *) = 0;
     virtual void read_blas_order(uint32_t, uint32_t *, uint32_t) = 0;
-    virtual void read_blas_boxes(uint32_t, float *, uint32_t) = 0;
+    virtual void read_blas_nodes(uint32_t, float *, float *, uint32_t *, uint32_t) = 0;
     virtual void render_phase(const lprt_frame_settings &, int phase) = 0;
     void render_frame(const lprt_frame_settings &fs) {
         render_phase(fs, LPRT_PHASE_SAMPLE);
@@ -91,7 +91,7 @@ struct CtxBase {
     uint32_t sample_first = 0, sample_rows = 0; // 0 rows: the whole window
     int next_phase = LPRT_PHASE_SAMPLE;
     // behaviour knobs (lprt_option): initialised from the environment once, in lprt_create; never read from it afterwards
-    int opts[LPRT_OPT_COUNT] = {-1, -1, 1, 0, 0, 1, 0, -1, 0, 12, 20, 0, (int)LPRT_MAX_SAMPLE_BATCH, 0, 1, 0, -1};
+    int opts[LPRT_OPT_COUNT] = {-1, -1, 1, 0, -1, 1, 0, -1, 0, 12, 20, 0, (int)LPRT_MAX_SAMPLE_BATCH, 0, 1, 0, -1};
     bool reference_slab() const { return opts[LPRT_OPT_REFERENCE_SLAB] != 0; }
     void options_from_environment() {
         if (const char *w = std::getenv("LPRT_WIDE_WALK"))
@@ -103,7 +103,7 @@ struct CtxBase {
         if (std::getenv("LPRT_SVGF_ALWAYS_TEST"))
             opts[LPRT_OPT_SVGF_ALWAYS_TEST] = 1;
         if (const char *b = std::getenv("LPRT_BLAS_BUILDER"))
-            opts[LPRT_OPT_BLAS_BUILDER] = std::string(b) == "morton" ? 1 : 0;
+            opts[LPRT_OPT_BLAS_BUILDER] = std::string(b) == "morton" ? 1 : std::string(b) == "sah" ? 2 : std::string(b) == "median" ? 0 : -1;
         if (const char *l = std::getenv("LPRT_BLAS_LOCAL"))
             opts[LPRT_OPT_BLAS_LOCAL] = std::string(l) == "0" ? 0 : 1;
         if (std::getenv("LPRT_DEBUG_SYNC"))
@@ -420,11 +420,23 @@ template <typename T> struct Impl : CtxBase {
     }
     // shadow rays walk deep BLAS trees two levels per step (trace.hpp); LPRT_OPT_WIDE_WALK overrides for A/B runs
     // GI / shadow rays as ray streams (stream.hpp): large scenes by default, LPRT_OPT_RAY_STREAM overrides
+    // which BLAS builder a build uses (LPRT_OPT_BLAS_BUILDER): -1 = the surface-area builder when some primitive is large enough for
+    // its hierarchy to matter (>= 64 triangles), the median split otherwise (the Cornell box: 2-12 triangles per primitive)
+    int builder_kind() const {
+        if (opts[LPRT_OPT_BLAS_BUILDER] >= 0)
+            return opts[LPRT_OPT_BLAS_BUILDER];
+        for (const BlasInfo &bi : geo.host_blas)
+            if (bi.n_tris >= 64u)
+                return 2;
+        return 0;
+    }
     bool ray_streams() const { return opts[LPRT_OPT_RAY_STREAM] < 0 ? geo.max_depth >= 6 : opts[LPRT_OPT_RAY_STREAM] != 0; }
     DevBuf d_stream_counters; // LPRT_STREAM_COUNTER_WORDS zeroed words per stream launch of a frame: 8 work counters, one per 64-byte line
     uint32_t stream_launches = 0;
     uint32_t *next_stream_counter() { return d_stream_counters.as<uint32_t>() + LPRT_STREAM_COUNTER_WORDS * (size_t)stream_launches++; }
-    bool wide_anyhit() const { return opts[LPRT_OPT_WIDE_WALK] < 0 ? geo.max_depth >= 6 : opts[LPRT_OPT_WIDE_WALK] != 0; }
+    // (the two-level walk reads the records of both children blindly: only the perfect trees of the median / Morton builders have them)
+    bool perfect_trees() const { return geo.layout_kind != 2; }
+    bool wide_anyhit() const { return perfect_trees() && (opts[LPRT_OPT_WIDE_WALK] < 0 ? geo.max_depth >= 6 : opts[LPRT_OPT_WIDE_WALK] != 0); }
     // ray sort (pipeline.hip): the items of a ray stream in (origin cell, direction octant) order.  Bit 0 of the option: GI rays,
     // bit 1: the shadow rays of round 1 (and of round 0 when they run as a stream); -1: both
     int ray_sort() const { return opts[LPRT_OPT_RAY_SORT] < 0 ? 0 : opts[LPRT_OPT_RAY_SORT]; } // measured: costs more than it buys (pipeline.hip)
@@ -467,7 +479,7 @@ template <typename T> struct Impl : CtxBase {
         const uint32_t batch_max = std::min<uint32_t>({spp, (uint32_t)opts[LPRT_OPT_SAMPLE_BATCH], LPRT_MAX_SAMPLE_BATCH});
         ensure_sample_slots(batch_max);
         if (fs.rebuild_blas) {
-            stage(LPRT_STAGE_BUILD_BLAS, [&] { geo.build_blas(stream, opts[LPRT_OPT_BLAS_BUILDER] == 1, opts[LPRT_OPT_BLAS_LOCAL] != 0); });
+            stage(LPRT_STAGE_BUILD_BLAS, [&] { geo.build_blas(stream, builder_kind(), opts[LPRT_OPT_BLAS_LOCAL] != 0); });
             objrecs_dirty = true;
             ensure_objrecs();
         }
@@ -483,7 +495,7 @@ template <typename T> struct Impl : CtxBase {
         };
         stage(LPRT_STAGE_PRIMARY, [&] { LPRT_TRACE(launch_fill_gbuffer)(stream, sc, fb, stage_counters(LPRT_STAGE_PRIMARY)); });
         const bool first = frame_index == 0;
-        const bool wide_walk = wide_anyhit(), streams = ray_streams(), wide_closest = opts[LPRT_OPT_STREAM_WIDE_CLOSEST] != 0;
+        const bool wide_walk = wide_anyhit(), streams = ray_streams(), wide_closest = perfect_trees() && opts[LPRT_OPT_STREAM_WIDE_CLOSEST] != 0;
         // round-0 shadow rays start on the camera-visible surface and aim at the same few lights: coherent, and the fused
         // per-pixel kernel serves them better (atrium: 7.5 vs 12.2 ms per frame) unless streams are forced on
         const bool stream_round0 = streams && opts[LPRT_OPT_RAY_STREAM] == 1;
@@ -722,7 +734,7 @@ template <typename T> struct Impl : CtxBase {
         }
     }
     void build_blas() override {
-        stage(LPRT_STAGE_BUILD_BLAS, [&] { geo.build_blas(stream, opts[LPRT_OPT_BLAS_BUILDER] == 1, opts[LPRT_OPT_BLAS_LOCAL] != 0); });
+        stage(LPRT_STAGE_BUILD_BLAS, [&] { geo.build_blas(stream, builder_kind(), opts[LPRT_OPT_BLAS_LOCAL] != 0); });
         objrecs_dirty = true;
     }
     void ensure_objrecs() {
@@ -805,7 +817,7 @@ template <typename T> struct Impl : CtxBase {
         sc.objects = d_objects.template as<ObjConst<T>>();
         sc.blas = geo.d_blas.template as<BlasInfo>();
         sc.blas_roots = geo.d_roots.template as<T>();
-        sc.blas_inner = geo.d_inner.template as<InnerNode<T>>();
+        sc.blas_inner = geo.d_inner.template as<BlasNode<T>>();
         sc.blas_leaf = geo.d_leaf.template as<uint32_t>();
         sc.tris = geo.d_tris.template as<TriRec<T>>();
         sc.tris_f32 = geo.d_tris_f32.template as<TriRecF32>();
@@ -844,12 +856,12 @@ template <typename T> struct Impl : CtxBase {
         LPRT_HIP(hipMemcpyAsync(d_rays.ptr, rays, sizeof(lprt_ray) * (size_t)n, hipMemcpyHostToDevice, stream));
         // the walk the frame kernels would take: any-hit batches follow wide_anyhit(); LPRT_OPT_WIDE_WALK = 1 also sends
         // closest-hit batches through the two-level walk (parity of that walk at hit-record level)
-        const bool wide = find_any ? wide_anyhit() : opts[LPRT_OPT_WIDE_WALK] == 1;
+        const bool wide = find_any ? wide_anyhit() : (perfect_trees() && opts[LPRT_OPT_WIDE_WALK] == 1);
         if (ray_streams()) { // the persistent traversal the frame kernels take in large scenes
             d_stream_counters.reserve(sizeof(uint32_t) * LPRT_STREAM_COUNTER_WORDS);
             LPRT_HIP(hipMemsetAsync(d_stream_counters.ptr, 0, sizeof(uint32_t) * LPRT_STREAM_COUNTER_WORDS, stream));
             LPRT_TRACE(launch_stream_rays)(stream, scene_dev(), d_rays.as<lprt_ray>(), n, find_any != 0,
-                                  find_any ? wide : (wide || opts[LPRT_OPT_STREAM_WIDE_CLOSEST] != 0), d_hits.as<lprt_hit>(),
+                                  find_any ? wide : (wide || (perfect_trees() && opts[LPRT_OPT_STREAM_WIDE_CLOSEST] != 0)), d_hits.as<lprt_hit>(),
                                   d_stream_counters.as<uint32_t>(), stage_counters(LPRT_STAGE_PRIMARY));
         } else {
             LPRT_TRACE(launch_trace_rays)(stream, scene_dev(), d_rays.as<lprt_ray>(), n, find_any != 0, wide, d_hits.as<lprt_hit>(),
@@ -922,7 +934,7 @@ template <typename T> struct Impl : CtxBase {
         const BlasInfo &bi = geo.host_blas[vao];
         *n_tris = bi.n_tris;
         *depth = bi.depth;
-        *n_nodes = bi.n_tris ? (2u << bi.depth) - 1 : 0;
+        *n_nodes = bi.n_tris ? (1u << bi.depth) - 1 : 0; // heap slots of the node records (depths 0 .. D-1)
     }
     void read_blas_order(uint32_t vao, uint32_t *order, uint32_t n) override {
         if (vao >= geo.n_vaos || !geo.built)
@@ -935,43 +947,43 @@ template <typename T> struct Impl : CtxBase {
         if (!order)
             throw std::string("null out pointer");
         // sorted values are global triangle ids; report primitive-local triangle indices
-        LPRT_HIP(hipMemcpyAsync(order, geo.d_vals[geo.sorted_buf].template as<uint32_t>() + bi.tri_base, sizeof(uint32_t) * (size_t)n,
+        LPRT_HIP(hipMemcpyAsync(order, geo.leaf_order() + bi.tri_base, sizeof(uint32_t) * (size_t)n,
                                 hipMemcpyDeviceToHost, stream));
         LPRT_HIP(hipStreamSynchronize(stream));
         for (uint32_t i = 0; i < n; i++)
             order[i] -= bi.tri_base;
     }
-    // heap order: box[0] = root, box[i-1] = node i; each 6 floats (lo, hi)
-    void read_blas_boxes(uint32_t vao, float *boxes, uint32_t n_nodes) override {
+    // node records in heap order (slot i at [i - 1], depths 0 .. D-1): both child boxes and both leaf words; root6 = the root box
+    void read_blas_nodes(uint32_t vao, float *root6, float *boxes, uint32_t *leaf_words, uint32_t n_slots) override {
         if (vao >= geo.n_vaos || !geo.built)
             throw std::string("bad vao index or BLAS not built");
         const BlasInfo &bi = geo.host_blas[vao];
-        uint32_t expect = bi.n_tris ? (2u << bi.depth) - 1 : 0;
-        if (n_nodes != expect)
+        const uint32_t expect = bi.n_tris ? (1u << bi.depth) - 1 : 0;
+        if (n_slots != expect)
             throw std::string("size mismatch");
-        if (!n_nodes)
-            return;
-        if (!boxes)
+        if (!root6 || (n_slots && (!boxes || !leaf_words)))
             throw std::string("null out pointer");
-        uint32_t n_inner = (1u << bi.depth) - 1;
-        std::vector<InnerNode<T>> inner(n_inner);
-        T root[6];
-        if (n_inner)
-            LPRT_HIP(hipMemcpyAsync(inner.data(), geo.d_inner.template as<InnerNode<T>>() + bi.inner_base, sizeof(InnerNode<T>) * n_inner,
+        std::vector<BlasNode<T>> inner(n_slots);
+        T root[6] = {};
+        if (n_slots)
+            LPRT_HIP(hipMemcpyAsync(inner.data(), geo.d_inner.template as<BlasNode<T>>() + bi.inner_base, sizeof(BlasNode<T>) * n_slots,
                                     hipMemcpyDeviceToHost, stream));
-        LPRT_HIP(hipMemcpyAsync(root, geo.d_roots.template as<T>() + 6 * bi.root_base, sizeof(root), hipMemcpyDeviceToHost, stream));
+        if (bi.n_tris)
+            LPRT_HIP(hipMemcpyAsync(root, geo.d_roots.template as<T>() + 6 * bi.root_base, sizeof(root), hipMemcpyDeviceToHost, stream));
         LPRT_HIP(hipStreamSynchronize(stream));
         for (int k = 0; k < 6; k++)
-            boxes[k] = (float)root[k];
-        for (uint32_t i = 1; i <= n_inner; i++) {
-            const InnerNode<T> &nd = inner[i - 1];
-            float *c0 = boxes + 6 * (2 * i - 1), *c1 = boxes + 6 * (2 * i);
+            root6[k] = (float)root[k];
+        for (uint32_t i = 0; i < n_slots; i++) {
+            const BlasNode<T> &nd = inner[i];
+            float *c0 = boxes + 12 * (size_t)i, *c1 = c0 + 6;
             for (int k = 0; k < 3; k++) {
                 c0[k] = (float)nd.lo0[k];
                 c0[3 + k] = (float)nd.hi0[k];
                 c1[k] = (float)nd.lo1[k];
                 c1[3 + k] = (float)nd.hi1[k];
             }
+            leaf_words[2 * (size_t)i] = nd.leaf[0];
+            leaf_words[2 * (size_t)i + 1] = nd.leaf[1];
         }
     }
 };
@@ -1308,6 +1320,12 @@ int lprt_set_option(lprt_ctx *ctx, lprt_option option, int value) {
         if ((int)option < 0 || (int)option >= LPRT_OPT_COUNT)
             throw std::string("unknown option");
         const bool tri = option == LPRT_OPT_WIDE_WALK || option == LPRT_OPT_TLAS_MODE || option == LPRT_OPT_RAY_STREAM; // -1 = automatic
+        if (option == LPRT_OPT_BLAS_BUILDER) {
+            if (value < -1 || value > 2)
+                throw std::string("option value out of range");
+            c.opts[option] = value;
+            return;
+        }
         if (option == LPRT_OPT_RAY_SORT) { // a bit set
             if (value < -1 || value > 3)
                 throw std::string("option value out of range");
@@ -1337,8 +1355,8 @@ int lprt_get_blas_info(lprt_ctx *ctx, uint32_t vao, uint32_t *n_tris, uint32_t *
 int lprt_read_blas_order(lprt_ctx *ctx, uint32_t vao, uint32_t *order, uint32_t n) {
     return guarded(ctx, [&](CtxBase &c) { c.read_blas_order(vao, order, n); });
 }
-int lprt_read_blas_boxes(lprt_ctx *ctx, uint32_t vao, float *boxes, uint32_t n_nodes) {
-    return guarded(ctx, [&](CtxBase &c) { c.read_blas_boxes(vao, boxes, n_nodes); });
+int lprt_read_blas_nodes(lprt_ctx *ctx, uint32_t vao, float *root6, float *boxes, uint32_t *leaf_words, uint32_t n_nodes) {
+    return guarded(ctx, [&](CtxBase &c) { c.read_blas_nodes(vao, root6, boxes, leaf_words, n_nodes); });
 }
 
 } // extern "C"

@@ -14,13 +14,17 @@ template <typename T> struct GeometryStore {
     std::vector<BlasInfo> host_blas;
     DevBuf d_vbo32, d_vbo, d_ebo, d_vaos, d_tri_prim, d_blas;
     DevBuf d_mf32, d_tri_bounds, d_sorted_bounds, d_prim_cbounds, d_keys[2], d_vals[2], d_hist;
-    DevBuf d_tris, d_tris_f32, d_inner, d_leaf, d_roots, d_seg_bounds, d_local_jobs, d_rank_bases;
+    DevBuf d_tris, d_tris_f32, d_inner, d_leaf, d_roots, d_seg_bounds, d_local_jobs, d_rank_bases, d_sah_nodes, d_fin;
+    int layout_kind = -1;   // which builder host_blas / d_blas are laid out for (set_layout)
+    int builder_hint = 0;   // the kind upload() lays out for (the context's builder option at upload time)
 
     // RDResource::{objects_vbo, objects_ebo, objects_vao} + vertex conversion (memory.hpp:568-619)
     void upload(hipStream_t st, const lprt_vertex *vbo, uint32_t nv, const uint32_t *ebo, uint32_t ni, const lprt_mesh_vao *vaos,
                 uint32_t nvaos);
     // compute_m + ObjectBVH for every primitive, all on the device
-    void build_blas(hipStream_t st, bool use_morton = false, bool use_local = true); // LPRT_OPT_BLAS_BUILDER / LPRT_OPT_BLAS_LOCAL
+    void build_blas(hipStream_t st, int kind = 0, bool use_local = true); // kind 0 median, 1 Morton, 2 surface-area (LPRT_OPT_BLAS_BUILDER); LPRT_OPT_BLAS_LOCAL
+    void set_layout(hipStream_t st, int kind);
+    const uint32_t *leaf_order() const { return sorted_buf == 2 ? d_fin.as<uint32_t>() : d_vals[sorted_buf].template as<uint32_t>(); }
     void radix_sort(hipStream_t st, const std::vector<int> &shifts, int &cur);
     // the plan of the median build (a function of the triangle counts and of use_local): made once, kept on the device
     bool plan_valid = false, plan_local = true, plan_dense = false;

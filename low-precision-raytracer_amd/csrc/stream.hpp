@@ -90,10 +90,13 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items_all
     // current instance
     RayT<T> lray{zero3<T>(), zero3<T>()};
     RaySlab<T> lrs{};
-    const InnerNode<T> *inner = nullptr;
+    const BlasNode<T> *inner = nullptr;
     uint32_t D = 0, n_tris = 0, tri_base = 0, obj_id = 0;
     bool skip_here = false;
-    uint32_t i = 1, c = 0;
+    // inside an instance: (i, c) the node to visit next while node_live; lf != 0: triangles to test first, (first << 3) | count
+    // (types.hpp: BlasNode -- leaves arrive with their parent's record and are never deferred); pend: deferred inner siblings
+    uint32_t i = 1, c = 0, lf = 0;
+    bool node_live = false;
     unsigned long long pend = 0;
     Isect<T> is;
     is.hit = false;
@@ -220,8 +223,8 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items_all
         // and its last ones run 200-400 steps with the lanes of the finished ones empty.
         const bool majority = sc.stream_sched != 0u;
         uint32_t n_entry = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(has_ray && !in_obj));
-        uint32_t n_node = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(in_obj && c < D));
-        uint32_t n_leaf = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(in_obj && c == D));
+        uint32_t n_node = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(in_obj && node_live && lf == 0u));
+        uint32_t n_leaf = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(in_obj && lf != 0u));
         const bool run_node = !majority || (n_node >= n_entry && n_node >= n_leaf);
         const bool run_leaf = !majority || (!run_node && n_leaf >= n_entry);
         const bool run_entry = !majority || (!run_node && !run_leaf);
@@ -329,6 +332,8 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items_all
                         i = 1;
                         c = 0;
                         pend = 0;
+                        lf = 0;
+                        node_live = true;
                         in_obj = true;
                         if (D <= 1u) { // 1-3 triangles: no boxes worth testing (trace.hpp)
                             for (uint32_t q = 0; q < n_tris; q++) {
@@ -344,11 +349,40 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items_all
             }
         }
         // ---- node steps: "while-while", left early when few lanes are still descending ----------------------------------
-        while (run_node && in_obj && c < D) {
-            bool dead = false;
+        // deferred sibling -> (i, c); false: nothing is pending
+        auto pop = [&]() -> bool {
+            if (!pend)
+                return false;
+            if (WIDE) {
+                const uint32_t bit = 63u - (uint32_t)__builtin_clzll(pend);
+                pend ^= 1ull << bit;
+                const uint32_t k2 = (bit >> 2) * 2u, j = bit & 3u;
+                const uint32_t anc = i >> (c - k2);
+                if (k2 + 2u <= D) {
+                    i = (anc << 2) | j;
+                    c = k2 + 2u;
+                } else {
+                    i = (anc << 1) | j;
+                    c = k2 + 1u;
+                }
+            } else {
+                const uint32_t d = 63u - (uint32_t)__builtin_clzll(pend);
+                pend ^= 1ull << d;
+                i = (i >> (c - d)) ^ 1u;
+                c = d;
+            }
+            return true;
+        };
+        while (run_node && in_obj && node_live && lf == 0u) {
             cnt.step(1);
-            if (WIDE && c + 2u <= D) {
-                const InnerNode<T> ra = inner[2 * i - 1], rb = inner[2 * i];
+            if (WIDE && c == D) {
+                // (perfect trees only) a leaf the two-level walk reached or had deferred: its range is a function of its index
+                uint32_t l, r;
+                leaf_range_dev(i - (1u << D), D, n_tris, l, r);
+                lf = (l << 3) | (r - l);
+                node_live = pop(); // what the walk goes on with after the triangles
+            } else if (WIDE && c + 2u <= D) {
+                const BlasNode<T> ra = inner[2 * i - 1], rb = inner[2 * i];
                 if (COUNT)
                     cnt.blas_nodes += 4;
                 float n[4];
@@ -373,52 +407,36 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items_all
                     i = 4 * i + first;
                     c += 2;
                 } else {
-                    dead = true;
+                    node_live = pop();
                 }
             } else {
-                const InnerNode<T> nd = inner[i - 1];
+                const BlasNode<T> nd = inner[i - 1];
                 if (COUNT)
                     cnt.blas_nodes += 2;
                 float n0, n1;
                 const float bt = (float)is.t, mn = (float)tmin, mx = (float)tmax;
                 const bool h0 = stream_box(nd.lo0, nd.hi0, lrs, bt, mn, mx, n0);
                 const bool h1 = stream_box(nd.lo1, nd.hi1, lrs, bt, mn, mx, n1);
-                if (h0 | h1) {
-                    const uint32_t first = (h0 && (!h1 || n0 <= n1)) ? 0u : 1u;
-                    if (h0 & h1)
+                const bool l0 = nd.leaf[0] != LPRT_CHILD_INNER, l1 = nd.leaf[1] != LPRT_CHILD_INNER;
+                if (h0 && l0)
+                    lf = nd.leaf[0];
+                if (h1 && l1)
+                    lf = lf ? lf + (nd.leaf[1] & 7u) : nd.leaf[1]; // sibling leaves are adjacent in leaf order
+                const bool g0 = h0 && !l0, g1 = h1 && !l1;
+                if (g0 | g1) {
+                    const uint32_t first = (g0 && (!g1 || n0 <= n1)) ? 0u : 1u;
+                    if (g0 & g1)
                         pend |= WIDE ? ((unsigned long long)(1u << (first ^ 1u)) << (2 * c)) : (1ull << (c + 1));
                     i = 2 * i + first;
                     c += 1;
                 } else {
-                    dead = true;
-                }
-            }
-            if (dead) {
-                if (!pend) {
-                    in_obj = false;
-                } else if (WIDE) {
-                    const uint32_t bit = 63u - (uint32_t)__builtin_clzll(pend);
-                    pend ^= 1ull << bit;
-                    const uint32_t k2 = (bit >> 2) * 2u, j = bit & 3u;
-                    const uint32_t anc = i >> (c - k2);
-                    if (k2 + 2u <= D) {
-                        i = (anc << 2) | j;
-                        c = k2 + 2u;
-                    } else {
-                        i = (anc << 1) | j;
-                        c = k2 + 1u;
-                    }
-                } else {
-                    const uint32_t d = 63u - (uint32_t)__builtin_clzll(pend);
-                    pend ^= 1ull << d;
-                    i = (i >> (c - d)) ^ 1u;
-                    c = d;
+                    node_live = pop();
                 }
             }
             if (majority) {
-                // stay while the descending lanes are still the largest group (lanes that reached a leaf or left their
+                // stay while the descending lanes are still the largest group (lanes that got triangles to test or left their
                 // instance during this step are counted where they now are)
-                const uint32_t now_node = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(in_obj && c < D));
+                const uint32_t now_node = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(node_live && lf == 0u));
                 const uint32_t moved = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) - now_node;
                 n_leaf += moved; // upper bound for either of the other groups: cheap, and errs towards leaving early
                 if (now_node < n_leaf || now_node < n_entry + moved)
@@ -428,37 +446,21 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items_all
             }
         }
         // ---- leaf: the wave tests triangles -----------------------------------------------------------------------------
-        if (run_leaf && in_obj && c == D) {
-            uint32_t l, r;
+        if (run_leaf && in_obj && lf != 0u) {
             cnt.step(2);
-            leaf_range_dev(i - (1u << D), D, n_tris, l, r);
+            const uint32_t l = lf >> 3, r = l + (lf & 7u);
+            lf = 0;
             for (uint32_t q = l; q < r; q++) {
                 const uint32_t rec = tri_base + q;
                 tri_test<T, COUNT>(sc, rec, lray, obj_id, is, tmin, tmax, cnt, skip_here, skip_off);
                 if (ANY && is.hit)
                     break;
             }
-            if ((ANY && is.hit) || !pend) {
-                in_obj = false;
-            } else if (WIDE) {
-                const uint32_t bit = 63u - (uint32_t)__builtin_clzll(pend);
-                pend ^= 1ull << bit;
-                const uint32_t k2 = (bit >> 2) * 2u, j = bit & 3u;
-                const uint32_t anc = i >> (c - k2);
-                if (k2 + 2u <= D) {
-                    i = (anc << 2) | j;
-                    c = k2 + 2u;
-                } else {
-                    i = (anc << 1) | j;
-                    c = k2 + 1u;
-                }
-            } else {
-                const uint32_t d = 63u - (uint32_t)__builtin_clzll(pend);
-                pend ^= 1ull << d;
-                i = (i >> (c - d)) ^ 1u;
-                c = d;
-            }
+            if (ANY && is.hit)
+                node_live = false;
         }
+        if (in_obj && !node_live && lf == 0u)
+            in_obj = false; // this instance is done: back to the top level
     }
 }
 

@@ -400,7 +400,7 @@ LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, const Ray
         cnt.blas_nodes++;
     if (!(slab_test<T, false, PAR>(ob.root_lo, ob.root_hi, rs, tmn, tmx) && tmn < (float)is.t && tmn < max_d && tmx > min_d))
         return;
-    const InnerNode<T> *inner = sc.blas_inner + ob.inner_base;
+    const BlasNode<T> *inner = sc.blas_inner + ob.inner_base;
     const uint32_t D = ob.depth;
     const bool skip_here = (ob.vao_index == skip_vao);
     if (D <= 1) {
@@ -426,7 +426,7 @@ LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, const Ray
             while (c < D) {
                 uint32_t h = 0, first = 0;
                 if (c + 2 <= D) {
-                    const InnerNode<T> ra = inner[2 * i - 1], rb = inner[2 * i];
+                    const BlasNode<T> ra = inner[2 * i - 1], rb = inner[2 * i];
                     if (COUNT)
                         cnt.blas_nodes += 4;
                     cnt.step(1);
@@ -457,7 +457,7 @@ LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, const Ray
                         continue;
                     }
                 } else { // one level left above the leaves
-                    const InnerNode<T> nd = inner[i - 1];
+                    const BlasNode<T> nd = inner[i - 1];
                     if (COUNT)
                         cnt.blas_nodes += 2;
                     float n0, x0, n1, x1;
@@ -502,57 +502,59 @@ LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, const Ray
             }
         }
     }
-    // "while-while": every lane first walks inner nodes until it stands on a leaf (or runs out of work), then the
-    // whole wave tests triangles; the two code paths are not interleaved per iteration.
+    // "while-while": every lane first walks inner nodes until it has triangles to test (or runs out of work), then the whole
+    // wave tests triangles; the two code paths are not interleaved per iteration.  A record carries a LEAF WORD per child
+    // (types.hpp: BlasNode): a hit child that is a leaf hands over its triangle range at once -- leaves sit at any depth, there
+    // is no record to fetch for them and they are never deferred; when both children are hit leaves their ranges are adjacent
+    // in leaf order and are tested as one.  Only INNER children are descended into (nearer first) or deferred (one pending bit
+    // per level: the tree is implicitly indexed, see the header of this file).
     uint32_t i = 1, c = 0, pending = 0;
-    bool alive = true;
-    while (alive) {
-        while (c < D) {
+    bool node_live = true; // (i, c) is a node still to be visited
+    for (;;) {
+        uint32_t lf = 0; // (first << 3) | count of the triangles to test now; 0: none
+        while (node_live && lf == 0u) {
             LPRT_CHECK(sc, ob.inner_base + i - 1 < sc.lim_inner, 203, ob.inner_base + i - 1, sc.lim_inner);
-            const InnerNode<T> nd = inner[i - 1];
+            const BlasNode<T> nd = inner[i - 1];
             if (COUNT)
                 cnt.blas_nodes += 2;
             cnt.step(1);
             float n0, x0, n1, x1;
             const float best_t = (float)is.t;
-            bool h0 = slab_test<T, false, PAR>(nd.lo0, nd.hi0, rs, n0, x0) && n0 < best_t && n0 < max_d && x0 > min_d;
-            bool h1 = slab_test<T, false, PAR>(nd.lo1, nd.hi1, rs, n1, x1) && n1 < best_t && n1 < max_d && x1 > min_d;
-            if (h0 | h1) {
-                uint32_t first = (h0 && (!h1 || n0 <= n1)) ? 0u : 1u;
-                if (h0 & h1)
+            const bool h0 = slab_test<T, false, PAR>(nd.lo0, nd.hi0, rs, n0, x0) && n0 < best_t && n0 < max_d && x0 > min_d;
+            const bool h1 = slab_test<T, false, PAR>(nd.lo1, nd.hi1, rs, n1, x1) && n1 < best_t && n1 < max_d && x1 > min_d;
+            const bool l0 = nd.leaf[0] != LPRT_CHILD_INNER, l1 = nd.leaf[1] != LPRT_CHILD_INNER;
+            if (h0 && l0)
+                lf = nd.leaf[0];
+            if (h1 && l1)
+                lf = lf ? lf + (nd.leaf[1] & 7u) : nd.leaf[1];
+            const bool g0 = h0 && !l0, g1 = h1 && !l1;
+            if (g0 | g1) {
+                const uint32_t first = (g0 && (!g1 || n0 <= n1)) ? 0u : 1u;
+                if (g0 & g1)
                     pending |= 1u << (c + 1);
                 i = 2 * i + first;
                 c++;
-            } else {
-                if (!pending) {
-                    alive = false;
-                    break;
-                }
-                uint32_t d = 31u - (uint32_t)__builtin_clz(pending);
+            } else if (pending) {
+                const uint32_t d = 31u - (uint32_t)__builtin_clz(pending);
                 pending ^= 1u << d;
                 i = (i >> (c - d)) ^ 1u;
                 c = d;
+            } else {
+                node_live = false;
             }
         }
-        if (!alive)
-            break;
-        {
-            uint32_t l, r;
+        if (lf) {
             cnt.step(2);
-            leaf_range_dev(i - (1u << D), D, ob.n_tris, l, r);
+            const uint32_t l = lf >> 3, r = l + (lf & 7u);
             for (uint32_t k = l; k < r; k++) {
-                uint32_t rec = ob.tri_base + k;
+                const uint32_t rec = ob.tri_base + k;
                 tri_test<T, COUNT>(sc, rec, ray, ob.inscene_objid, is, min_distance, max_distance, cnt, skip_here, skip_off);
                 if (ANY && is.hit)
                     return;
             }
         }
-        if (!pending)
-            break;
-        uint32_t d = 31u - (uint32_t)__builtin_clz(pending);
-        pending ^= 1u << d;
-        i = (i >> (c - d)) ^ 1u;
-        c = d;
+        if (!node_live)
+            return;
     }
 }
 

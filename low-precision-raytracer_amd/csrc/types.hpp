@@ -35,11 +35,28 @@ struct alignas(16) TriRecF32 { // 48 B
 template <typename T> struct alignas(sizeof(T) * 4) InnerNode { // 48 B (f32) / 24 B (f16)
     T lo0[3], hi0[3], lo1[3], hi1[3];
 };
+// One node of a BLAS: the boxes of both children and, per child, a LEAF WORD -- LPRT_CHILD_INNER when the child is an inner
+// node (its own record sits at heap slot 2i + k: no child pointers), else (first << 3) | count: the child is a leaf holding
+// `count` (0..7; 0 = no child, box inverted) triangles from `first` on, relative to the primitive's first TriRec, in leaf
+// order.  Leaves can sit at any depth <= D (the surface-area builder stops as soon as a node holds <= 2 triangles), and a
+// leaf needs no record of its own: what a ray needs to test its triangles arrives with the parent's record, in the fetch that
+// brought the leaf's box.  32 B (f16) / 64 B (f32): one or two 32-byte sectors, never straddling a 128-byte line.
+#define LPRT_CHILD_INNER 0xffffffffu
+template <typename T> struct BlasNode;
+template <> struct alignas(32) BlasNode<h16> {
+    h16 lo0[3], hi0[3], lo1[3], hi1[3];
+    uint32_t leaf[2];
+};
+template <> struct alignas(64) BlasNode<float> {
+    float lo0[3], hi0[3], lo1[3], hi1[3];
+    uint32_t leaf[2], pad[2];
+};
+static_assert(sizeof(BlasNode<h16>) == 32 && sizeof(BlasNode<float>) == 64, "BlasNode layout");
 struct BlasInfo {
     uint32_t n_tris;     // 0: empty primitive
-    uint32_t depth;      // D
+    uint32_t depth;      // D: no node lies deeper (median builder: every leaf at exactly D; surface-area builder: an upper bound)
     uint32_t tri_base;   // first TriRec of this primitive (sorted order)
-    uint32_t inner_base; // first InnerNode (2^D - 1 of them)
+    uint32_t inner_base; // first BlasNode (2^D - 1 heap slots: nodes of depth 0 .. D-1)
     uint32_t leaf_base;  // first leaf word (2^D of them): (first_sorted_tri << 1) | (count - 1)
     uint32_t root_base;  // index of the root box in root_boxes
     uint32_t pad[2];
@@ -102,7 +119,7 @@ template <typename T> struct SceneDev {
     // BLAS
     const BlasInfo *blas;
     const T *blas_roots; // 6 scalars per primitive
-    const InnerNode<T> *blas_inner;
+    const BlasNode<T> *blas_inner;
     const uint32_t *blas_leaf;
     const TriRec<T> *tris;
     const TriRecF32 *tris_f32; // half instantiation only

@@ -65,7 +65,7 @@ SYMBOLS = [
     ("lprt_reset_stage_times", C.c_int, [_P]),
     ("lprt_get_blas_info", C.c_int, [_P, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("lprt_read_blas_order", C.c_int, [_P, C.c_uint32, _P, C.c_uint32]),
-    ("lprt_read_blas_boxes", C.c_int, [_P, C.c_uint32, _P, C.c_uint32]),
+    ("lprt_read_blas_nodes", C.c_int, [_P, C.c_uint32, _P, _P, _P, C.c_uint32]),
     ("lprt_version", C.c_char_p, []),
 ]
 
@@ -368,8 +368,9 @@ class Renderer:
         self._check(self.L.lprt_read_blas_order(self.h, vao, _ptr(out), n), "lprt_read_blas_order")
         return out
 
-    def blas_boxes(self, vao):
+    def blas_nodes(self, vao):
+        """(root box [6], child boxes [n_nodes, 2, 6], leaf words [n_nodes, 2]) of the heap-ordered node records (include/lprt.h)."""
         n = self.blas_info(vao)["n_nodes"]
-        out = _out((n, 6), np.float32)
-        self._check(self.L.lprt_read_blas_boxes(self.h, vao, _ptr(out), n), "lprt_read_blas_boxes")
-        return out
+        root, boxes, words = _out(6, np.float32), _out((n, 2, 6), np.float32), _out((n, 2), np.uint32)
+        self._check(self.L.lprt_read_blas_nodes(self.h, vao, _ptr(root), _ptr(boxes), _ptr(words), n), "lprt_read_blas_nodes")
+        return root, boxes, words

@@ -190,7 +190,10 @@ def test_atrium_frames_with_per_frame_rebuild_match_oracle_ray_by_ray(sponza, pr
         for s_ in range(spp):
             assert not (c["gi_other_ray"][s_] & ~c["primary"]).any(), (f, s_)
         j = replay.adjudicate_gi(c, probe_o)
-        assert j["neither"] <= 2 and j["gpu_lost"] <= max(8, j["oracle_lost"]), (f, j)
+        # (both walks lose a nearest hit now and then -- the half triangle test places t within ~1e-3 relative, a box entry can
+        # lie beyond the running closest t although a triangle inside computes a smaller one: `neither` -- but the GPU's f32
+        # slab parameters on outward-rounded boxes lose fewer than the reference's half ones)
+        assert j["neither"] <= 2 + 0.01 * j["disputed"] and j["gpu_lost"] <= max(8, j["oracle_lost"]), f"frame {f}: {sorted(j.items())}"
         assert_planes_ray_by_ray(r, o, c, prec, kept_l2=1e-4, kept_px=1e-2, max_outliers=0)
         for name in RADIANCE:
             lim = min(ATRIUM_F16_CEILING[name], TOL[prec]) if name in ("COLOR_INPROGRESS", "OUTPUT") else ATRIUM_F16_CEILING[name]
@@ -674,7 +677,7 @@ def test_render_phases_and_sample_rows_are_checked(cornell):
 def test_options_out_array_sizes_and_null_pointers_are_checked(cornell):
     import ctypes as C
     with lprt_amd.Renderer(32, 32, abi.F32) as r:
-        assert [r.get_option(n) for n in abi.OPTIONS] == [-1, -1, 1, 0, 0, 1, 0, -1, 0, 12, 20, 0, 8, 0, 1, 0, -1]
+        assert [r.get_option(n) for n in abi.OPTIONS] == [-1, -1, 1, 0, -1, 1, 0, -1, 0, 12, 20, 0, 8, 0, 1, 0, -1]
         r.set_option("wide_walk", 1)
         assert r.get_option("wide_walk") == 1
         with pytest.raises(lprt_amd.LprtError, match="out of range"):

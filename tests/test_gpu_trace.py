@@ -48,12 +48,16 @@ def compare_hits(ho, hg, any_hit, max_tie_frac):
     return int(ties.sum())
 
 
-@pytest.mark.parametrize("scene_name,n", [("cornell", 60000), ("small_test", 60000), ("sponza_like", 40000)])
-def test_fp32_hit_records_match_oracle(scene_name, n):
+@pytest.mark.parametrize("scene_name,n,builder", [("cornell", 60000, -1), ("small_test", 60000, -1), ("small_test", 60000, 2), ("sponza_like", 40000, 0),
+                                                   ("sponza_like", 40000, 2)])
+def test_fp32_hit_records_match_oracle(scene_name, n, builder):
+    """builder: LPRT_OPT_BLAS_BUILDER (-1 the default choice, 0 median split, 2 surface-area heuristic): the hierarchy is a
+    matter of speed, the hit records are the oracle's either way (exact-t ties excepted)."""
     sc = scenes.SCENES[scene_name]()
     o = Oracle(16, 16, abi.F32)
     o.load_scene(sc)
     r = lprt_amd.Renderer(16, 16, abi.F32)
+    r.set_option("blas_builder", builder)
     r.load_scene(sc)
     rays = random_rays(sc, n, 11, 1e-4)
     for any_hit in (False, True):  # any-hit batches take the walk the frame kernels take: two levels per step on the atrium
@@ -150,6 +154,7 @@ def test_two_level_walk_reports_the_hits_of_the_one_level_walk(sponza, prec):
     hits = {}
     for wide in (0, 1):
         with lprt_amd.Renderer(16, 16, prec) as r:
+            r.set_option("blas_builder", 0)  # the two-level walk exists for the perfect trees of the median builder
             r.set_option("wide_walk", wide)
             r.load_scene(sponza)
             r.enable_counters(True)
@@ -215,33 +220,47 @@ def test_skip_geometry_and_distance_window(cornell):
     assert hg["hit"][2] == 0 and hg["hit"][3] == 0
 
 
-def test_blas_is_a_valid_hierarchy(sponza):
-    """GPU build (B1): sorted order is a permutation, every leaf box contains its triangles, every parent contains
-    its children; depth = floor(log2 n)."""
+@pytest.mark.parametrize("builder", ["median", "sah"])
+def test_blas_is_a_valid_hierarchy(sponza, builder):
+    """GPU build (B1), both builders: the leaf order is a permutation; walking the node records from the root (children of
+    slot i at 2i, 2i + 1; a leaf word per child) every triangle lies in exactly one leaf, every leaf holds 1..2 triangles,
+    every child box contains its triangles (leaf) or both of its own child boxes (inner node), and no node lies deeper than
+    the depth the BLAS reports.  Median builder: depth = floor(log2 n) and every leaf at that depth; surface-area builder:
+    depth bound ceil(log2(ceil(n / 2))) + 1, leaves wherever a node has <= 2 triangles left."""
+    INNER = 0xFFFFFFFF
     r = lprt_amd.Renderer(16, 16, abi.F32)
+    r.set_option("blas_builder", {"median": 0, "sah": 2}[builder])
     r.set_rdresource(sponza)
     pos = sponza.vertices["position"]
     for vao in (0, 4, 8, 23):
         info = r.blas_info(vao)
-        n = info["n_tris"]
-        assert n == sponza.vaos[vao][3] // 3 and info["depth"] == int(np.floor(np.log2(n))) and info["n_nodes"] == (2 << info["depth"]) - 1
+        n, D = info["n_tris"], info["depth"]
+        assert n == sponza.vaos[vao][3] // 3 and info["n_nodes"] == (1 << D) - 1
+        assert D == (int(np.floor(np.log2(n))) if builder == "median" else int(np.ceil(np.log2(np.ceil(n / 2)))) + 1)
         order = r.blas_order(vao)
         assert np.array_equal(np.sort(order), np.arange(n))
-        boxes = r.blas_boxes(vao)
-        D = info["depth"]
+        root, boxes, words = r.blas_nodes(vao)
         tri = pos[sponza.indices[sponza.vaos[vao][2]:sponza.vaos[vao][2] + 3 * n].reshape(n, 3)]  # [n,3,3]
         tlo, thi = tri.min(axis=1)[order], tri.max(axis=1)[order]
-        # leaf ranges: split at l + (r-l)//2 down D levels
-        bounds = [(0, n)]
-        for _ in range(D):
-            bounds = [x for (l, rr) in bounds for x in ((l, l + (rr - l) // 2), (l + (rr - l) // 2, rr))]
-        first = (1 << D) - 1
-        for k, (l, rr) in enumerate(bounds):
-            assert 1 <= rr - l <= 2
-            assert (boxes[first + k, :3] <= tlo[l:rr].min(axis=0)).all() and (boxes[first + k, 3:] >= thi[l:rr].max(axis=0)).all()
-        for i in range(first):
-            for c in (2 * i + 1, 2 * i + 2):
-                assert (boxes[i, :3] <= boxes[c, :3]).all() and (boxes[i, 3:] >= boxes[c, 3:]).all()
+        seen = np.zeros(n, dtype=np.int32)
+        leaf_depths = []
+        stack = [(1, 0, root)]
+        while stack:
+            i, d, box = stack.pop()
+            assert i <= (1 << D) - 1 and d < D
+            for k in (0, 1):
+                cb, w = boxes[i - 1, k], int(words[i - 1, k])
+                assert (box[:3] <= cb[:3]).all() and (box[3:] >= cb[3:]).all(), (vao, i, k)
+                if w == INNER:
+                    stack.append((2 * i + k, d + 1, cb))
+                else:
+                    first, cnt = w >> 3, w & 7
+                    assert 1 <= cnt <= 2
+                    seen[first:first + cnt] += 1
+                    leaf_depths.append(d + 1)
+                    assert (cb[:3] <= tlo[first:first + cnt].min(axis=0)).all() and (cb[3:] >= thi[first:first + cnt].max(axis=0)).all()
+        assert (seen == 1).all()
+        assert max(leaf_depths) <= D and (builder == "sah" or min(leaf_depths) == D)
 
 
 def test_ragged_and_tiny_primitives():
@@ -371,6 +390,7 @@ def test_local_subtree_ordering_equals_the_all_global_build(sponza, small_scene)
         orders = {}
         for mode in ("0", "1"):
             r = lprt_amd.Renderer(16, 16, abi.F32)
+            r.set_option("blas_builder", 0)  # the median builder (the atrium's default is the surface-area builder)
             r.set_option("blas_local", int(mode))
             r.set_rdresource(sc)
             orders[mode] = [r.blas_order(v) for v in range(len(sc.vaos))]

@@ -86,7 +86,7 @@ static int build_rec(Blas &b, std::vector<Tri> &t, int l, int r, int d, int D, c
     out_box = nb;
     b.max_depth = std::max(b.max_depth, d);
     const int n = r - l;
-    bool leaf = pm.mode == 0 ? d == D : n <= pm.L;
+    bool leaf = pm.mode != 1 ? d == D : n <= pm.L;
     if (leaf) {
         out_first = l;
         out_cnt = n;
@@ -98,8 +98,9 @@ static int build_rec(Blas &b, std::vector<Tri> &t, int l, int r, int d, int D, c
         axis = (w[1] > w[0] && w[1] > w[2]) ? 1 : (w[2] > w[0] && w[2] > w[1]) ? 2 : 0;
         std::stable_sort(t.begin() + l, t.begin() + r, [&](const Tri &a, const Tri &c) { return a.centroid()[axis] < c.centroid()[axis]; });
     } else {
-        // capacity of a child subtree: L * 2^(levels below the child)
-        const long long cap = (long long)pm.L << std::max(0, D - d - 1);
+        // capacity of a child subtree: L * 2^(levels below the child); mode 2 (perfect tree): every leaf needs at least one
+        const long long cap = (long long)(pm.mode == 2 ? 2 : pm.L) << std::max(0, D - d - 1);
+        const long long need = pm.mode == 2 ? (1ll << std::max(0, D - d - 1)) : 1;
         Box cbx;
         for (int i = l; i < r; i++)
             cbx.add(t[i].centroid());
@@ -133,7 +134,7 @@ static int build_rec(Blas &b, std::vector<Tri> &t, int l, int r, int d, int D, c
                 pre.add(bb[k]);
                 pc += bc[k];
                 const int rc = sufc[k + 1];
-                if (pc == 0 || rc == 0 || pc > cap || rc > cap)
+                if (pc < need || rc < need || pc > cap || rc > cap)
                     continue;
                 const double cost = pre.area() * (double)pc + suf[k + 1].area() * (double)rc;
                 if (cost < best) {
@@ -172,7 +173,7 @@ static Blas build(const std::vector<Tri> &src, const Params &pm) {
     b.tris = src;
     const int n = (int)src.size();
     int D = 0;
-    if (pm.mode == 0) {
+    if (pm.mode != 1) {
         while ((2 << D) <= n)
             D++; // floor(log2 n)
     } else {
@@ -333,7 +334,7 @@ int main(int argc, char **argv) {
             prims[p].push_back(t);
         }
     }
-    std::vector<Params> cfgs = {{0, 2, 0, 0}, {1, 2, 1, 32}, {1, 2, 3, 32}, {1, 4, 2, 32}, {1, 4, 4, 32}, {1, 4, 8, 32}, {1, 4, 4, 16}, {1, 8, 4, 32}, {1, 1, 4, 32}};
+    std::vector<Params> cfgs = {{0, 2, 0, 0}, {2, 2, 0, 32}, {2, 2, 0, 128}, {1, 2, 1, 32}, {1, 2, 3, 32}, {1, 4, 2, 32}, {1, 4, 4, 32}, {1, 4, 8, 32}, {1, 4, 4, 16}, {1, 8, 4, 32}, {1, 1, 4, 32}};
     const int W = 256, H = 144;
     for (const Params &pm : cfgs) {
         std::vector<Blas> bl(np);

@@ -9,6 +9,7 @@ for name in ("sponza_like", "small_test", "cornell", "instanced_field"):
     orders, times = {}, {}
     for mode in ("0", "1"):
         r = lprt_amd.Renderer(64, 64, abi.F32)
+        r.set_option("blas_builder", 0)
         r.set_option("blas_local", int(mode))
         r.set_rdresource(sc)            # builds once (warm-up: allocations)
         r.enable_stage_timing(True)
