@@ -118,6 +118,10 @@ struct CtxBase {
             opts[LPRT_OPT_STREAM_XCD] = r[0] == '0' ? 0 : 1;
         if (const char *r = std::getenv("LPRT_STREAM_SCHED"))
             opts[LPRT_OPT_STREAM_SCHED] = r[0] == '1' ? 1 : 0;
+        if (const char *r = std::getenv("LPRT_STREAM_NODE_MIN"))
+            opts[LPRT_OPT_STREAM_NODE_MIN] = std::max(1, std::min(64, std::atoi(r)));
+        if (const char *r = std::getenv("LPRT_STREAM_REFILL_MIN"))
+            opts[LPRT_OPT_STREAM_REFILL_MIN] = std::max(1, std::min(64, std::atoi(r)));
         if (const char *r = std::getenv("LPRT_RAY_SORT"))
             opts[LPRT_OPT_RAY_SORT] = std::max(0, std::min(3, std::atoi(r)));
         if (const char *r = std::getenv("LPRT_REFERENCE_SLAB"))
@@ -434,9 +438,7 @@ template <typename T> struct Impl : CtxBase {
     DevBuf d_stream_counters; // LPRT_STREAM_COUNTER_WORDS zeroed words per stream launch of a frame: 8 work counters, one per 64-byte line
     uint32_t stream_launches = 0;
     uint32_t *next_stream_counter() { return d_stream_counters.as<uint32_t>() + LPRT_STREAM_COUNTER_WORDS * (size_t)stream_launches++; }
-    // (the two-level walk reads the records of both children blindly: only the perfect trees of the median / Morton builders have them)
-    bool perfect_trees() const { return geo.layout_kind != 2; }
-    bool wide_anyhit() const { return perfect_trees() && (opts[LPRT_OPT_WIDE_WALK] < 0 ? geo.max_depth >= 6 : opts[LPRT_OPT_WIDE_WALK] != 0); }
+    bool wide_anyhit() const { return opts[LPRT_OPT_WIDE_WALK] < 0 ? geo.max_depth >= 6 : opts[LPRT_OPT_WIDE_WALK] != 0; }
     // ray sort (pipeline.hip): the items of a ray stream in (origin cell, direction octant) order.  Bit 0 of the option: GI rays,
     // bit 1: the shadow rays of round 1 (and of round 0 when they run as a stream); -1: both
     int ray_sort() const { return opts[LPRT_OPT_RAY_SORT] < 0 ? 0 : opts[LPRT_OPT_RAY_SORT]; } // measured: costs more than it buys (pipeline.hip)
@@ -495,7 +497,7 @@ template <typename T> struct Impl : CtxBase {
         };
         stage(LPRT_STAGE_PRIMARY, [&] { LPRT_TRACE(launch_fill_gbuffer)(stream, sc, fb, stage_counters(LPRT_STAGE_PRIMARY)); });
         const bool first = frame_index == 0;
-        const bool wide_walk = wide_anyhit(), streams = ray_streams(), wide_closest = perfect_trees() && opts[LPRT_OPT_STREAM_WIDE_CLOSEST] != 0;
+        const bool wide_walk = wide_anyhit(), streams = ray_streams(), wide_closest = opts[LPRT_OPT_STREAM_WIDE_CLOSEST] != 0;
         // round-0 shadow rays start on the camera-visible surface and aim at the same few lights: coherent, and the fused
         // per-pixel kernel serves them better (atrium: 7.5 vs 12.2 ms per frame) unless streams are forced on
         const bool stream_round0 = streams && opts[LPRT_OPT_RAY_STREAM] == 1;
@@ -856,12 +858,12 @@ template <typename T> struct Impl : CtxBase {
         LPRT_HIP(hipMemcpyAsync(d_rays.ptr, rays, sizeof(lprt_ray) * (size_t)n, hipMemcpyHostToDevice, stream));
         // the walk the frame kernels would take: any-hit batches follow wide_anyhit(); LPRT_OPT_WIDE_WALK = 1 also sends
         // closest-hit batches through the two-level walk (parity of that walk at hit-record level)
-        const bool wide = find_any ? wide_anyhit() : (perfect_trees() && opts[LPRT_OPT_WIDE_WALK] == 1);
+        const bool wide = find_any ? wide_anyhit() : (opts[LPRT_OPT_WIDE_WALK] == 1);
         if (ray_streams()) { // the persistent traversal the frame kernels take in large scenes
             d_stream_counters.reserve(sizeof(uint32_t) * LPRT_STREAM_COUNTER_WORDS);
             LPRT_HIP(hipMemsetAsync(d_stream_counters.ptr, 0, sizeof(uint32_t) * LPRT_STREAM_COUNTER_WORDS, stream));
             LPRT_TRACE(launch_stream_rays)(stream, scene_dev(), d_rays.as<lprt_ray>(), n, find_any != 0,
-                                  find_any ? wide : (wide || (perfect_trees() && opts[LPRT_OPT_STREAM_WIDE_CLOSEST] != 0)), d_hits.as<lprt_hit>(),
+                                  find_any ? wide : (wide || opts[LPRT_OPT_STREAM_WIDE_CLOSEST] != 0), d_hits.as<lprt_hit>(),
                                   d_stream_counters.as<uint32_t>(), stage_counters(LPRT_STAGE_PRIMARY));
         } else {
             LPRT_TRACE(launch_trace_rays)(stream, scene_dev(), d_rays.as<lprt_ray>(), n, find_any != 0, wide, d_hits.as<lprt_hit>(),

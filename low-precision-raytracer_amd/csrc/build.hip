@@ -942,6 +942,26 @@ __global__ void __launch_bounds__(GW == 1u ? 256 : 64 * GW) k_sah_level(const Bl
         nd.leaf[0] = nl <= SAH_LEAF ? ((l << 3) | nl) : LPRT_CHILD_INNER;
         nd.leaf[1] = nr <= SAH_LEAF ? (((l + nl) << 3) | nr) : LPRT_CHILD_INNER;
         inner[bi.inner_base + slot - 1u] = nd;
+        // A child that is a leaf gets a record of its own as well (entry 0: its box and leaf word; entry 1: a far-away point
+        // with no triangles), so that the two-level walk can fetch the records of BOTH children of a node without knowing what
+        // they are (trace.hpp).  Slots exist for depths < D.
+        if (d + 1u < bi.depth) {
+            const T far_ = round_down<T>(60000.0f);
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+                if (nd.leaf[k] != LPRT_CHILD_INNER) {
+                    BlasNode<T> lr;
+#pragma unroll
+                    for (int x = 0; x < 3; x++) {
+                        lr.lo0[x] = k ? nd.lo1[x] : nd.lo0[x];
+                        lr.hi0[x] = k ? nd.hi1[x] : nd.hi0[x];
+                        lr.lo1[x] = lr.hi1[x] = far_;
+                    }
+                    lr.leaf[0] = nd.leaf[k];
+                    lr.leaf[1] = 0u;
+                    inner[bi.inner_base + 2u * slot + (uint32_t)k - 1u] = lr;
+                }
+        }
         pn[2u * slot] = SahNode{l, nl};
         pn[2u * slot + 1u] = SahNode{l + nl, nr};
         if (d == 0u) {

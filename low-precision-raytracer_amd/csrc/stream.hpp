@@ -95,7 +95,7 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items_all
     bool skip_here = false;
     // inside an instance: (i, c) the node to visit next while node_live; lf != 0: triangles to test first, (first << 3) | count
     // (types.hpp: BlasNode -- leaves arrive with their parent's record and are never deferred); pend: deferred inner siblings
-    uint32_t i = 1, c = 0, lf = 0;
+    uint32_t i = 1, c = 0, lf = 0, lf2 = 0; // (lf2: the second child record's leaves in the two-level walk)
     bool node_live = false;
     unsigned long long pend = 0;
     Isect<T> is;
@@ -223,8 +223,8 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items_all
         // and its last ones run 200-400 steps with the lanes of the finished ones empty.
         const bool majority = sc.stream_sched != 0u;
         uint32_t n_entry = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(has_ray && !in_obj));
-        uint32_t n_node = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(in_obj && node_live && lf == 0u));
-        uint32_t n_leaf = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(in_obj && lf != 0u));
+        uint32_t n_node = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(in_obj && node_live && (lf | lf2) == 0u));
+        uint32_t n_leaf = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(in_obj && (lf | lf2) != 0u));
         const bool run_node = !majority || (n_node >= n_entry && n_node >= n_leaf);
         const bool run_leaf = !majority || (!run_node && n_leaf >= n_entry);
         const bool run_entry = !majority || (!run_node && !run_leaf);
@@ -332,7 +332,7 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items_all
                         i = 1;
                         c = 0;
                         pend = 0;
-                        lf = 0;
+                        lf = lf2 = 0;
                         node_live = true;
                         in_obj = true;
                         if (D <= 1u) { // 1-3 triangles: no boxes worth testing (trace.hpp)
@@ -356,15 +356,9 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items_all
             if (WIDE) {
                 const uint32_t bit = 63u - (uint32_t)__builtin_clzll(pend);
                 pend ^= 1ull << bit;
-                const uint32_t k2 = (bit >> 2) * 2u, j = bit & 3u;
-                const uint32_t anc = i >> (c - k2);
-                if (k2 + 2u <= D) {
-                    i = (anc << 2) | j;
-                    c = k2 + 2u;
-                } else {
-                    i = (anc << 1) | j;
-                    c = k2 + 1u;
-                }
+                const uint32_t k2 = (bit >> 2) * 2u, j = bit & 3u; // depth of the node the step started from, grandchild slot
+                i = ((i >> (c - k2)) << 2) | j;
+                c = k2 + 2u;
             } else {
                 const uint32_t d = 63u - (uint32_t)__builtin_clzll(pend);
                 pend ^= 1ull << d;
@@ -373,37 +367,40 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items_all
             }
             return true;
         };
-        while (run_node && in_obj && node_live && lf == 0u) {
+        while (run_node && in_obj && node_live && (lf | lf2) == 0u) {
             cnt.step(1);
-            if (WIDE && c == D) {
-                // (perfect trees only) a leaf the two-level walk reached or had deferred: its range is a function of its index
-                uint32_t l, r;
-                leaf_range_dev(i - (1u << D), D, n_tris, l, r);
-                lf = (l << 3) | (r - l);
-                node_live = pop(); // what the walk goes on with after the triangles
-            } else if (WIDE && c + 2u <= D) {
+            if (WIDE && c + 2u <= D) {
+                // two levels per step (trace.hpp): the records of both children, whatever the children are
                 const BlasNode<T> ra = inner[2 * i - 1], rb = inner[2 * i];
                 if (COUNT)
                     cnt.blas_nodes += 4;
                 float n[4];
-                uint32_t h = 0;
                 const float bt = (float)is.t, mn = (float)tmin, mx = (float)tmax;
-                h |= stream_box(ra.lo0, ra.hi0, lrs, bt, mn, mx, n[0]) ? 1u : 0u;
-                h |= stream_box(ra.lo1, ra.hi1, lrs, bt, mn, mx, n[1]) ? 2u : 0u;
-                h |= stream_box(rb.lo0, rb.hi0, lrs, bt, mn, mx, n[2]) ? 4u : 0u;
-                h |= stream_box(rb.lo1, rb.hi1, lrs, bt, mn, mx, n[3]) ? 8u : 0u;
-                if (h) {
+                const bool h0 = stream_box(ra.lo0, ra.hi0, lrs, bt, mn, mx, n[0]), h1 = stream_box(ra.lo1, ra.hi1, lrs, bt, mn, mx, n[1]);
+                const bool h2 = stream_box(rb.lo0, rb.hi0, lrs, bt, mn, mx, n[2]), h3 = stream_box(rb.lo1, rb.hi1, lrs, bt, mn, mx, n[3]);
+                const bool l0 = ra.leaf[0] != LPRT_CHILD_INNER, l1 = ra.leaf[1] != LPRT_CHILD_INNER;
+                const bool l2 = rb.leaf[0] != LPRT_CHILD_INNER, l3 = rb.leaf[1] != LPRT_CHILD_INNER;
+                if (h0 && l0)
+                    lf = ra.leaf[0];
+                if (h1 && l1)
+                    lf = lf ? lf + (ra.leaf[1] & 7u) : ra.leaf[1];
+                if (h2 && l2)
+                    lf2 = rb.leaf[0];
+                if (h3 && l3)
+                    lf2 = lf2 ? lf2 + (rb.leaf[1] & 7u) : rb.leaf[1];
+                const uint32_t g = ((h0 && !l0) ? 1u : 0u) | ((h1 && !l1) ? 2u : 0u) | ((h2 && !l2) ? 4u : 0u) | ((h3 && !l3) ? 8u : 0u);
+                if (g) {
                     uint32_t first = 0;
                     float best = __builtin_inff();
                     bool have = false;
 #pragma unroll
                     for (uint32_t q = 0; q < 4; q++)
-                        if (((h >> q) & 1u) && (!have || n[q] < best)) {
+                        if (((g >> q) & 1u) && (!have || n[q] < best)) {
                             best = n[q];
                             first = q;
                             have = true;
                         }
-                    pend |= (unsigned long long)(h & ~(1u << first)) << (2 * c);
+                    pend |= (unsigned long long)(g & ~(1u << first)) << (2 * c);
                     i = 4 * i + first;
                     c += 2;
                 } else {
@@ -422,11 +419,11 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items_all
                     lf = nd.leaf[0];
                 if (h1 && l1)
                     lf = lf ? lf + (nd.leaf[1] & 7u) : nd.leaf[1]; // sibling leaves are adjacent in leaf order
-                const bool g0 = h0 && !l0, g1 = h1 && !l1;
+                const bool g0 = h0 && !l0 && !WIDE, g1 = h1 && !l1 && !WIDE; // (two-level walk: this is the last level, all leaves)
                 if (g0 | g1) {
                     const uint32_t first = (g0 && (!g1 || n0 <= n1)) ? 0u : 1u;
                     if (g0 & g1)
-                        pend |= WIDE ? ((unsigned long long)(1u << (first ^ 1u)) << (2 * c)) : (1ull << (c + 1));
+                        pend |= 1ull << (c + 1);
                     i = 2 * i + first;
                     c += 1;
                 } else {
@@ -436,7 +433,7 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items_all
             if (majority) {
                 // stay while the descending lanes are still the largest group (lanes that got triangles to test or left their
                 // instance during this step are counted where they now are)
-                const uint32_t now_node = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(node_live && lf == 0u));
+                const uint32_t now_node = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(node_live && (lf | lf2) == 0u));
                 const uint32_t moved = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) - now_node;
                 n_leaf += moved; // upper bound for either of the other groups: cheap, and errs towards leaving early
                 if (now_node < n_leaf || now_node < n_entry + moved)
@@ -446,20 +443,27 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items_all
             }
         }
         // ---- leaf: the wave tests triangles -----------------------------------------------------------------------------
-        if (run_leaf && in_obj && lf != 0u) {
+        if (run_leaf && in_obj && (lf | lf2) != 0u) {
             cnt.step(2);
+            if (lf == 0u) { // (only the two-level walk fills lf2)
+                lf = lf2;
+                lf2 = 0;
+            }
             const uint32_t l = lf >> 3, r = l + (lf & 7u);
-            lf = 0;
+            lf = WIDE ? lf2 : 0u; // the second range, if any, in the next pass
+            lf2 = 0;
             for (uint32_t q = l; q < r; q++) {
                 const uint32_t rec = tri_base + q;
                 tri_test<T, COUNT>(sc, rec, lray, obj_id, is, tmin, tmax, cnt, skip_here, skip_off);
                 if (ANY && is.hit)
                     break;
             }
-            if (ANY && is.hit)
+            if (ANY && is.hit) {
                 node_live = false;
+                lf = 0;
+            }
         }
-        if (in_obj && !node_live && lf == 0u)
+        if (in_obj && !node_live && (lf | lf2) == 0u)
             in_obj = false; // this instance is done: back to the top level
     }
 }

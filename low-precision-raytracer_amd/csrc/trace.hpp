@@ -371,20 +371,6 @@ LPRT_DEV bool tri_test(const SceneDev<T> &sc, uint32_t rec, const RayT<T> &ray, 
     return false;
 }
 
-// sorted range [l, r) of leaf k in the perfect tree of depth D over n primitives (csrc/build.hip::leaf_range): computed,
-// not loaded — one dependent fetch less per leaf
-LPRT_DEV void leaf_range_dev(uint32_t k, uint32_t D, uint32_t n, uint32_t &l, uint32_t &r) {
-    l = 0;
-    r = n;
-    for (int b = (int)D - 1; b >= 0; b--) {
-        uint32_t mid = l + ((r - l) >> 1);
-        if ((k >> b) & 1u)
-            l = mid;
-        else
-            r = mid;
-    }
-}
-
 // ---- T4: BLAS traversal (replaces search_intersection_in_object, cuda.hpp:415-504) -----------------
 template <typename T, bool ANY, bool COUNT, bool PAR, bool WIDE>
 LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, const RaySlab<T> &rs, const ObjHead<T> &ob, uint32_t skip_vao,
@@ -416,47 +402,56 @@ LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, const Ray
     // Two levels per step: the records of both children of node i are adjacent (heap order), and together they hold the four
     // GRANDCHILD boxes.  A grandchild box lies inside its parent's box and the slab test is monotone in the bounds, so a ray
     // that passes a grandchild box passes the child box too: the child boxes need not be tested.  One dependent fetch and
-    // four box tests per two levels instead of two fetches and four to six tests; the deferred siblings of a step are four
-    // bits of a 64-bit mask (node 4i + j), popped deepest first.
+    // four box tests per two levels instead of two fetches and four to six tests; the deferred INNER grandchildren of a step
+    // are four bits of a 64-bit mask (node 4i + j), popped deepest first; hit LEAF grandchildren hand over their triangles at
+    // once, one range per child record (sibling leaves are adjacent in leaf order).  Works on every tree the builders make:
+    // a child that is itself a leaf has a record too (its own box and leaf word in entry 0, nothing in entry 1:
+    // build.hip), so the two records can be fetched without knowing what the children are.
     if (WIDE) {
         uint32_t i = 1, c = 0;
         unsigned long long pend = 0;
+        bool node_live = true;
         for (;;) {
-            bool dead = false;
-            while (c < D) {
-                uint32_t h = 0, first = 0;
+            uint32_t lfa = 0, lfb = 0;
+            while (node_live && (lfa | lfb) == 0u) {
+                cnt.step(1);
+                uint32_t g = 0, first = 0; // hit INNER children of this step, the nearest of them
                 if (c + 2 <= D) {
                     const BlasNode<T> ra = inner[2 * i - 1], rb = inner[2 * i];
                     if (COUNT)
                         cnt.blas_nodes += 4;
-                    cnt.step(1);
                     float n[4], x;
                     const float best_t = (float)is.t;
-                    bool hh;
-                    hh = slab_test<T, false, PAR>(ra.lo0, ra.hi0, rs, n[0], x) && n[0] < best_t && n[0] < max_d && x > min_d;
-                    h |= hh ? 1u : 0u;
-                    hh = slab_test<T, false, PAR>(ra.lo1, ra.hi1, rs, n[1], x) && n[1] < best_t && n[1] < max_d && x > min_d;
-                    h |= hh ? 2u : 0u;
-                    hh = slab_test<T, false, PAR>(rb.lo0, rb.hi0, rs, n[2], x) && n[2] < best_t && n[2] < max_d && x > min_d;
-                    h |= hh ? 4u : 0u;
-                    hh = slab_test<T, false, PAR>(rb.lo1, rb.hi1, rs, n[3], x) && n[3] < best_t && n[3] < max_d && x > min_d;
-                    h |= hh ? 8u : 0u;
-                    if (h) {
+                    const bool h0 = slab_test<T, false, PAR>(ra.lo0, ra.hi0, rs, n[0], x) && n[0] < best_t && n[0] < max_d && x > min_d;
+                    const bool h1 = slab_test<T, false, PAR>(ra.lo1, ra.hi1, rs, n[1], x) && n[1] < best_t && n[1] < max_d && x > min_d;
+                    const bool h2 = slab_test<T, false, PAR>(rb.lo0, rb.hi0, rs, n[2], x) && n[2] < best_t && n[2] < max_d && x > min_d;
+                    const bool h3 = slab_test<T, false, PAR>(rb.lo1, rb.hi1, rs, n[3], x) && n[3] < best_t && n[3] < max_d && x > min_d;
+                    const bool l0 = ra.leaf[0] != LPRT_CHILD_INNER, l1 = ra.leaf[1] != LPRT_CHILD_INNER;
+                    const bool l2 = rb.leaf[0] != LPRT_CHILD_INNER, l3 = rb.leaf[1] != LPRT_CHILD_INNER;
+                    if (h0 && l0)
+                        lfa = ra.leaf[0];
+                    if (h1 && l1)
+                        lfa = lfa ? lfa + (ra.leaf[1] & 7u) : ra.leaf[1];
+                    if (h2 && l2)
+                        lfb = rb.leaf[0];
+                    if (h3 && l3)
+                        lfb = lfb ? lfb + (rb.leaf[1] & 7u) : rb.leaf[1];
+                    g = ((h0 && !l0) ? 1u : 0u) | ((h1 && !l1) ? 2u : 0u) | ((h2 && !l2) ? 4u : 0u) | ((h3 && !l3) ? 8u : 0u);
+                    if (g) {
                         float best = __builtin_inff();
                         bool have = false;
 #pragma unroll
                         for (uint32_t k = 0; k < 4; k++)
-                            if (((h >> k) & 1u) && (!have || n[k] < best)) {
+                            if (((g >> k) & 1u) && (!have || n[k] < best)) {
                                 best = n[k];
                                 first = k;
                                 have = true;
                             }
-                        pend |= (unsigned long long)(h & ~(1u << first)) << (2 * c); // bits 4*(c/2) ..: c is even here
+                        pend |= (unsigned long long)(g & ~(1u << first)) << (2 * c); // bits 4*(c/2) ..: c is even here
                         i = 4 * i + first;
                         c += 2;
-                        continue;
                     }
-                } else { // one level left above the leaves
+                } else { // one level left: the children are leaves (no node lies deeper than D)
                     const BlasNode<T> nd = inner[i - 1];
                     if (COUNT)
                         cnt.blas_nodes += 2;
@@ -464,42 +459,38 @@ LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, const Ray
                     const float best_t = (float)is.t;
                     const bool h0 = slab_test<T, false, PAR>(nd.lo0, nd.hi0, rs, n0, x0) && n0 < best_t && n0 < max_d && x0 > min_d;
                     const bool h1 = slab_test<T, false, PAR>(nd.lo1, nd.hi1, rs, n1, x1) && n1 < best_t && n1 < max_d && x1 > min_d;
-                    if (h0 | h1) {
-                        first = (h0 && (!h1 || n0 <= n1)) ? 0u : 1u;
-                        if (h0 & h1)
-                            pend |= (unsigned long long)(1u << (first ^ 1u)) << (2 * c);
-                        i = 2 * i + first;
-                        c += 1;
-                        continue;
+                    if (h0 && nd.leaf[0] != LPRT_CHILD_INNER)
+                        lfa = nd.leaf[0];
+                    if (h1 && nd.leaf[1] != LPRT_CHILD_INNER)
+                        lfa = lfa ? lfa + (nd.leaf[1] & 7u) : nd.leaf[1];
+                }
+                if (!g) { // nothing to descend into: the deepest deferred grandchild, if any
+                    if (!pend) {
+                        node_live = false;
+                    } else {
+                        const uint32_t bit = 63u - (uint32_t)__builtin_clzll(pend);
+                        pend ^= 1ull << bit;
+                        const uint32_t k2 = (bit >> 2) * 2, j = bit & 3u; // depth of the node the step started from, grandchild slot
+                        i = ((i >> (c - k2)) << 2) | j;
+                        c = k2 + 2;
                     }
                 }
-                dead = true; // nothing hit below this node
-                break;
             }
-            if (!dead) {
-                uint32_t l, r;
+            if (lfa | lfb)
                 cnt.step(2);
-                leaf_range_dev(i - (1u << D), D, ob.n_tris, l, r);
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const uint32_t lf = q ? lfb : lfa;
+                const uint32_t l = lf >> 3, r = l + (lf & 7u);
                 for (uint32_t k = l; k < r; k++) {
-                    uint32_t rec = ob.tri_base + k;
+                    const uint32_t rec = ob.tri_base + k;
                     tri_test<T, COUNT>(sc, rec, ray, ob.inscene_objid, is, min_distance, max_distance, cnt, skip_here, skip_off);
                     if (ANY && is.hit)
                         return;
                 }
             }
-            if (!pend)
+            if (!node_live)
                 return;
-            const uint32_t bit = 63u - (uint32_t)__builtin_clzll(pend);
-            pend ^= 1ull << bit;
-            const uint32_t k2 = (bit >> 2) * 2, j = bit & 3u; // depth of the node the step started from, child slot
-            const uint32_t anc = i >> (c - k2);
-            if (k2 + 2 <= D) {
-                i = (anc << 2) | j;
-                c = k2 + 2;
-            } else {
-                i = (anc << 1) | j;
-                c = k2 + 1;
-            }
         }
     }
     // "while-while": every lane first walks inner nodes until it has triangles to test (or runs out of work), then the whole
