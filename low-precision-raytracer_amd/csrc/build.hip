@@ -656,18 +656,44 @@ template <typename T> __global__ void k_inner_level(const BlasInfo *blas, uint32
 // Level by level, ONE WAVE PER NODE: pass 1 centroid bounds, pass 2 binning (LDS atomics, 336 words per wave), 45 lanes
 // evaluate the 45 planes, pass 3 a stable partition (ballot ranks) that also yields the exact child boxes.  The node's record
 // -- both child boxes and both leaf words -- is complete when its wave ends: no bottom-up refit.
-constexpr uint32_t SAH_BINS = 16, SAH_LEAF = 2;
-struct SahNode {
-    uint32_t start, count; // triangles [start, start + count) of the primitive's current order; count 0: no such node
+constexpr uint32_t SAH_BINS = 16, SAH_LEAF = 2, SAH_BIG = 256, SAH_ONE_AXIS = 4096;
+// An open node (more than SAH_LEAF triangles) waiting for its level: queue entry.  lo / hi: the domain its centroids are binned
+// over -- the centroid bounds of the primitive for a root (k_tri_prepare), the exact box of its triangles for every other node
+// (the parent's partition pass computes it anyway; a pass of its own over the centroids bought nothing measurable in tree
+// quality: tools/bvh_quality.cpp).
+struct SahItem {
+    uint32_t prim, slot, start, count;
+    float lo[3], hi[3];
+    uint32_t pad[2];
 };
-__host__ __device__ inline uint32_t sah_node_base(const BlasInfo &bi, uint32_t prim) { return 2u * (bi.inner_base + prim); } // 2^(D+1) slots each
-__global__ void k_sah_init(const BlasInfo *blas, uint32_t n_vaos, SahNode *nodes) {
+// queues of one build: [kind 0: nodes of <= SAH_BIG triangles, one wave each | kind 1: larger, one workgroup each][level parity]
+struct SahQueues {
+    SahItem *items[2][2];
+    uint32_t *count; // [2 kinds][levels + 1]
+    uint32_t levels;
+};
+__device__ __forceinline__ void sah_push(const SahQueues &q, uint32_t level, const SahItem &it) {
+    const uint32_t kind = it.count > SAH_BIG ? 1u : 0u;
+    const uint32_t pos = atomicAdd(q.count + kind * (q.levels + 1u) + level, 1u);
+    q.items[kind][level & 1u][pos] = it;
+}
+__global__ void k_sah_init(const BlasInfo *blas, uint32_t n_vaos, const int *prim_cbounds, SahQueues q) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_vaos)
         return;
     const BlasInfo bi = blas[p];
-    if (bi.n_tris > 3u)
-        nodes[sah_node_base(bi, p) + 1u] = SahNode{0u, bi.n_tris};
+    if (bi.n_tris <= 3u)
+        return;
+    SahItem it{};
+    it.prim = p;
+    it.slot = 1u;
+    it.start = 0u;
+    it.count = bi.n_tris;
+    for (int k = 0; k < 3; k++) {
+        it.lo[k] = f32_unordered(prim_cbounds[6 * p + k]);
+        it.hi[k] = f32_unordered(prim_cbounds[6 * p + 3 + k]);
+    }
+    sah_push(q, 0u, it);
 }
 __device__ __forceinline__ float wave_min(float v) {
     for (int off = 32; off > 0; off >>= 1)
@@ -683,96 +709,73 @@ __device__ __forceinline__ float box_area(const float lo[3], const float hi[3]) 
     const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
     return dx * dy + dy * dz + dz * dx;
 }
-// src / dst: the two halves of the ping-pong order (level d reads the one, writes the other); fin: receives every level's
-// arrangement as well -- a position's LAST write is its leaf's, so after the last level `fin` is the leaf order.
-// GW = waves that share a node: 1 (four nodes per 256-thread workgroup: the many small nodes of the lower levels) or 16 (one
-// 1024-thread workgroup per node: the few nodes of the upper levels, up to 47 k triangles each on the atrium -- a single wave
-// spent 2 ms on the root alone).  A launch takes the nodes with min_count < count <= max_count.
+// One level: the open nodes of queue (kind, d), one group of GW waves each.  src / dst: the two halves of the ping-pong order
+// (level d reads the one, writes the other); fin receives every level's arrangement as well -- a position's LAST write is its
+// leaf's, so after the last level `fin` is the leaf order.
+// GW = 1 (kind 0, sixteen nodes per 1024-thread workgroup, a wave each: the many nodes of <= SAH_BIG triangles) or 16 (kind 1,
+// one 1024-thread workgroup per node: up to 47 k triangles on the atrium).  Nodes above SAH_ONE_AXIS triangles bin the widest
+// axis of their domain only -- 7 LDS atomics per triangle instead of 21, on a few addresses all 16 waves fight over -- which
+// is where the plane of such a node lies anyway (tools/bvh_quality.cpp: +1 % box tests with EVERY node restricted so).
 template <typename T, uint32_t GW>
-__global__ void __launch_bounds__(GW == 1u ? 256 : 64 * GW) k_sah_level(const BlasInfo *blas, uint32_t n_vaos, uint32_t d, uint32_t min_count, uint32_t max_count,
-                                                                         SahNode *nodes, const uint32_t *src, uint32_t *dst, uint32_t *fin,
-                                                                         const float *tri_bounds, BlasNode<T> *inner, T *roots) {
-    constexpr uint32_t NPB = GW == 1u ? 4u : 1u, GT = 64u * GW; // nodes per workgroup, threads per node
+__global__ void __launch_bounds__(1024) k_sah_level(const BlasInfo *blas, uint32_t d, SahQueues q, const uint32_t *src, uint32_t *dst,
+                                                                         uint32_t *fin, const float *tri_bounds, BlasNode<T> *inner, T *roots) {
+    constexpr uint32_t NPB = GW == 1u ? 16u : 1u, GT = 64u * GW, KIND = GW == 1u ? 0u : 1u; // nodes per workgroup, threads per node
     __shared__ int s_bins[NPB][3][SAH_BINS][7]; // per node: count, lo[3], hi[3] (bounds in order-preserving int space)
-    __shared__ int s_red[NPB][12];              // group reductions (GW > 1)
-    __shared__ uint32_t s_part[2][GW + 1u];     // per-wave left / right counts of a partition chunk (GW > 1)
+    __shared__ int s_red[NPB][12];                 // group reductions (GW > 1)
+    __shared__ uint32_t s_part[2][GW + 1u];        // per-wave left / right counts of a partition chunk (GW > 1)
     __shared__ uint32_t s_best[4];
+    __shared__ uint32_t s_push[2]; // GW == 1: open children of the workgroup's 16 nodes, reserved with ONE global atomic
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     const uint32_t grp = GW == 1u ? wv : 0u, t = GW == 1u ? lane : threadIdx.x;
     const uint32_t w = blockIdx.x * NPB + grp;
-    const uint32_t p = w >> d, j = w & ((1u << d) - 1u);
-    if (p >= n_vaos)
+    if (GW == 1u) {
+        if (threadIdx.x == 0u)
+            s_push[0] = 0u;
+        __syncthreads();
+    }
+    // children that stay open, filled by the group's first thread and queued for the next level at the end
+    SahItem open_child[2];
+    uint32_t n_open = 0;
+    const bool active = w < q.count[KIND * (q.levels + 1u) + d];
+    if (GW > 1u && !active)
         return;
+    if (active) {
+    const SahItem it = q.items[KIND][d & 1u][w];
+    const uint32_t p = it.prim, slot = it.slot, l = it.start, n = it.count;
     const BlasInfo bi = blas[p];
-    if (bi.n_tris <= 3u || d >= bi.depth)
-        return;
-    const uint32_t slot = (1u << d) + j;
-    SahNode *pn = nodes + sah_node_base(bi, p);
-    const SahNode st = pn[slot];
-    if (st.count <= min_count || st.count > max_count)
-        return; // no such node, a leaf (its parent wrote the leaf word), or the other launch's
     auto sync = [&]() {
         if (GW == 1u)
             __builtin_amdgcn_wave_barrier(); // (the LDS operations of a wave execute in order)
         else
             __syncthreads();
     };
-    const uint32_t l = st.start, n = st.count;
     const uint32_t *perm = src + bi.tri_base + l;
     int(*bins)[SAH_BINS][7] = s_bins[grp];
-    for (uint32_t q = t; q < 3u * SAH_BINS * 7u; q += GT) {
-        const uint32_t f = q % 7u;
-        (&bins[0][0][0])[q] = f == 0u ? 0 : (f < 4u ? 0x7fffffff : (int)0x80000000);
+    // nodes above SAH_ONE_AXIS triangles bin the widest axis of their domain only (see above)
+    const uint32_t n_axes = (GW > 1u && n > SAH_ONE_AXIS) ? 1u : 3u;
+    for (uint32_t qi = t; qi < 3u * SAH_BINS * 7u; qi += GT) {
+        const uint32_t f = qi % 7u;
+        (&bins[0][0][0])[qi] = f == 0u ? 0 : (f < 4u ? 0x7fffffff : (int)0x80000000);
     }
-    if (GW > 1u && t < 12u)
-        s_red[grp][t] = t < 6u ? (t < 3u ? 0x7fffffff : (int)0x80000000) : (t < 9u ? 0x7fffffff : (int)0x80000000);
-    // pass 1: bounds of the centroids
-    float cmin[3] = {3.4e38f, 3.4e38f, 3.4e38f}, cmax[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
-    for (uint32_t e = t; e < n; e += GT) {
-        const float *b = tri_bounds + 6 * (size_t)perm[e];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const float c = 0.5f * (b[k] + b[3 + k]);
-            cmin[k] = fminf(cmin[k], c);
-            cmax[k] = fmaxf(cmax[k], c);
-        }
-    }
+    float cmin[3], ext[3], scale[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        cmin[k] = wave_min(cmin[k]);
-        cmax[k] = wave_max(cmax[k]);
-    }
-    if (GW > 1u) {
-        __syncthreads(); // s_red is initialised
-        if (lane == 0u)
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                atomicMin(&s_red[grp][k], f32_ordered(cmin[k]));
-                atomicMax(&s_red[grp][3 + k], f32_ordered(cmax[k]));
-            }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            cmin[k] = f32_unordered(s_red[grp][k]);
-            cmax[k] = f32_unordered(s_red[grp][3 + k]);
-        }
-    }
-    float ext[3], scale[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        ext[k] = cmax[k] - cmin[k];
+        cmin[k] = it.lo[k];
+        ext[k] = it.hi[k] - it.lo[k];
         scale[k] = ext[k] > 0.f ? (float)SAH_BINS / ext[k] : 0.f;
     }
+    // the axis a big node bins: the widest of its domain (x on ties)
+    const uint32_t wide_axis = (ext[1] > ext[0] && ext[1] > ext[2]) ? 1u : (ext[2] > ext[0] && ext[2] > ext[1]) ? 2u : 0u;
     sync(); // the bins are initialised
-    // pass 2: binning
+    // pass 1: binning
     for (uint32_t e = t; e < n; e += GT) {
         const float *b = tri_bounds + 6 * (size_t)perm[e];
         float lo[3] = {b[0], b[1], b[2]}, hi[3] = {b[3], b[4], b[5]};
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
+        for (uint32_t ai = 0; ai < n_axes; ai++) {
+            const uint32_t a = n_axes == 3u ? ai : wide_axis;
             const float c = 0.5f * (lo[a] + hi[a]);
-            const uint32_t k = min((uint32_t)((c - cmin[a]) * scale[a]), SAH_BINS - 1u);
-            int *bn = bins[a][k];
+            const uint32_t k = min((uint32_t)fmaxf((c - cmin[a]) * scale[a], 0.f), SAH_BINS - 1u);
+            int *bn = bins[ai][k];
             atomicAdd(bn, 1);
 #pragma unroll
             for (int x = 0; x < 3; x++) {
@@ -782,19 +785,20 @@ __global__ void __launch_bounds__(GW == 1u ? 256 : 64 * GW) k_sah_level(const Bl
         }
     }
     sync();
-    // the 3 x 15 planes, one per lane of the first wave: everything in bins <= plane goes left
+    // the planes, one per lane of the first wave: everything in bins <= plane goes left
     const uint32_t cap = SAH_LEAF << (bi.depth - d - 1u); // what a child's subtree can hold
     uint32_t by_plane_u = 0, axis = 0, plane = 0, nl = n / 2u;
     if (GW == 1u || wv == 0u) {
         float cost = __builtin_inff();
         uint32_t nl_lane = 0;
-        if (lane < 3u * (SAH_BINS - 1u)) {
-            const uint32_t a = lane / (SAH_BINS - 1u), pl = lane % (SAH_BINS - 1u);
+        if (lane < n_axes * (SAH_BINS - 1u)) {
+            const uint32_t ai = lane / (SAH_BINS - 1u), pl = lane % (SAH_BINS - 1u);
+            const uint32_t a = n_axes == 3u ? ai : wide_axis;
             float llo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, lhi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
             float rlo[3] = {3.4e38f, 3.4e38f, 3.4e38f}, rhi[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
             uint32_t cl = 0, cr = 0;
             for (uint32_t k = 0; k < SAH_BINS; k++) {
-                const int *bn = bins[a][k];
+                const int *bn = bins[ai][k];
                 const uint32_t c = (uint32_t)bn[0];
                 if (!c)
                     continue;
@@ -829,7 +833,7 @@ __global__ void __launch_bounds__(GW == 1u ? 256 : 64 * GW) k_sah_level(const Bl
         }
         // no admissible plane (coincident centroids, or every plane overfills a side): the object median by position
         by_plane_u = best < __builtin_inff() ? 1u : 0u;
-        axis = by_plane_u ? best_lane / (SAH_BINS - 1u) : 0u;
+        axis = by_plane_u ? (n_axes == 3u ? best_lane / (SAH_BINS - 1u) : wide_axis) : 0u;
         plane = by_plane_u ? best_lane % (SAH_BINS - 1u) : 0u;
         nl = by_plane_u ? (uint32_t)__shfl((int)nl_lane, (int)best_lane, 64) : n / 2u;
         if (GW > 1u && lane == 0u) {
@@ -847,7 +851,7 @@ __global__ void __launch_bounds__(GW == 1u ? 256 : 64 * GW) k_sah_level(const Bl
         nl = s_best[3];
     }
     const bool by_plane = by_plane_u != 0u;
-    // pass 3: stable partition + the exact boxes of both sides
+    // pass 2: stable partition + the exact boxes of both sides
     float blo[2][3] = {{3.4e38f, 3.4e38f, 3.4e38f}, {3.4e38f, 3.4e38f, 3.4e38f}}, bhi[2][3] = {{-3.4e38f, -3.4e38f, -3.4e38f}, {-3.4e38f, -3.4e38f, -3.4e38f}};
     uint32_t out_l = 0, out_r = 0;
     uint32_t *o1 = dst + bi.tri_base + l, *o2 = fin + bi.tri_base + l;
@@ -862,7 +866,7 @@ __global__ void __launch_bounds__(GW == 1u ? 256 : 64 * GW) k_sah_level(const Bl
             const float *b = tri_bounds + 6 * (size_t)g;
             if (by_plane) {
                 const float c = 0.5f * (b[axis] + b[3 + axis]);
-                left = min((uint32_t)((c - cmin[axis]) * scale[axis]), SAH_BINS - 1u) <= plane;
+                left = min((uint32_t)fmaxf((c - cmin[axis]) * scale[axis], 0.f), SAH_BINS - 1u) <= plane;
             } else {
                 left = e < nl;
             }
@@ -882,10 +886,10 @@ __global__ void __launch_bounds__(GW == 1u ? 256 : 64 * GW) k_sah_level(const Bl
             }
             __syncthreads();
             tot_l = tot_r = 0;
-            for (uint32_t q = 0; q < GW; q++) {
-                const uint32_t a = s_part[0][q], c = s_part[1][q];
-                before_l += q < wv ? a : 0u;
-                before_r += q < wv ? c : 0u;
+            for (uint32_t qi = 0; qi < GW; qi++) {
+                const uint32_t a = s_part[0][qi], c = s_part[1][qi];
+                before_l += qi < wv ? a : 0u;
+                before_r += qi < wv ? c : 0u;
                 tot_l += a;
                 tot_r += c;
             }
@@ -944,12 +948,12 @@ __global__ void __launch_bounds__(GW == 1u ? 256 : 64 * GW) k_sah_level(const Bl
         inner[bi.inner_base + slot - 1u] = nd;
         // A child that is a leaf gets a record of its own as well (entry 0: its box and leaf word; entry 1: a far-away point
         // with no triangles), so that the two-level walk can fetch the records of BOTH children of a node without knowing what
-        // they are (trace.hpp).  Slots exist for depths < D.
-        if (d + 1u < bi.depth) {
-            const T far_ = round_down<T>(60000.0f);
+        // they are (trace.hpp).  Slots exist for depths < D.  An open child goes to the next level's queue.
+        const T far_ = round_down<T>(60000.0f);
 #pragma unroll
-            for (int k = 0; k < 2; k++)
-                if (nd.leaf[k] != LPRT_CHILD_INNER) {
+        for (int k = 0; k < 2; k++) {
+            if (nd.leaf[k] != LPRT_CHILD_INNER) {
+                if (d + 1u < bi.depth) {
                     BlasNode<T> lr;
 #pragma unroll
                     for (int x = 0; x < 3; x++) {
@@ -961,9 +965,23 @@ __global__ void __launch_bounds__(GW == 1u ? 256 : 64 * GW) k_sah_level(const Bl
                     lr.leaf[1] = 0u;
                     inner[bi.inner_base + 2u * slot + (uint32_t)k - 1u] = lr;
                 }
+            } else {
+                SahItem c{};
+                c.prim = p;
+                c.slot = 2u * slot + (uint32_t)k;
+                c.start = k ? l + nl : l;
+                c.count = k ? nr : nl;
+#pragma unroll
+                for (int x = 0; x < 3; x++) {
+                    c.lo[x] = blo[k][x];
+                    c.hi[x] = bhi[k][x];
+                }
+                if (GW == 1u)
+                    open_child[n_open++] = c;
+                else
+                    sah_push(q, d + 1u, c); // a handful of big nodes per level: one atomic each
+            }
         }
-        pn[2u * slot] = SahNode{l, nl};
-        pn[2u * slot + 1u] = SahNode{l + nl, nr};
         if (d == 0u) {
             T *rb = roots + 6 * bi.root_base;
 #pragma unroll
@@ -972,6 +990,22 @@ __global__ void __launch_bounds__(GW == 1u ? 256 : 64 * GW) k_sah_level(const Bl
                 rb[3 + x] = round_up<T>(fmaxf(bhi[0][x], bhi[1][x]));
             }
         }
+    }
+    } // active
+    if (GW == 1u) {
+        // Tens of thousands of small nodes per level: one device-scope atomic per node on the level's counter serialised into
+        // 0.1-0.4 ms per level (rocprofv3 trace of the first form).  The 16 nodes of a workgroup reserve their children's queue
+        // slots together: an LDS atomic each, one global atomic for the workgroup.  (Children of small nodes are small.)
+        uint32_t local = 0;
+        if (lane == 0u && n_open)
+            local = atomicAdd(&s_push[0], n_open);
+        __syncthreads();
+        if (threadIdx.x == 0u && s_push[0])
+            s_push[1] = atomicAdd(q.count + d + 1u, s_push[0]);
+        __syncthreads();
+        if (lane == 0u)
+            for (uint32_t k = 0; k < n_open; k++)
+                q.items[0][(d + 1u) & 1u][s_push[1] + local + k] = open_child[k];
     }
 }
 // primitives of <= 3 triangles have no records (the walk tests their triangles directly); their root boxes
@@ -1249,7 +1283,7 @@ template <typename T> void GeometryStore<T>::set_layout(hipStream_t st, int kind
     d_inner.reserve(sizeof(BlasNode<T>) * (size_t)std::max(n_inner, 1u));
     d_leaf.reserve(sizeof(uint32_t) * (size_t)std::max(n_leaves, 1u));
     if (kind == 2) {
-        d_sah_nodes.reserve(sizeof(SahNode) * 2u * ((size_t)n_inner + n_vaos + 1u));
+        d_sah_nodes.reserve(4096u + 2u * sizeof(SahItem) * ((size_t)n_tris / (SAH_LEAF + 1u) + n_vaos) + 2u * sizeof(SahItem) * ((size_t)n_tris / (SAH_BIG + 1u) + n_vaos));
         d_fin.reserve(sizeof(uint32_t) * (size_t)std::max(n_tris, 1u));
     }
     if (n_vaos) {
@@ -1352,24 +1386,41 @@ template <typename T> void GeometryStore<T>::build_blas(hipStream_t st, int kind
                        d_tri_prim.as<uint32_t>(), d_mf32.as<TriRecF32>(), d_tri_bounds.as<float>(), d_prim_cbounds.as<int>());
     int cur = 0;
     if (kind == 2) {
-        // surface-area builder: one launch per level, one wave per node (k_sah_level)
-        (void)hipMemsetAsync(d_sah_nodes.ptr, 0, sizeof(SahNode) * 2u * ((size_t)n_inner + n_vaos + 1u), st);
+        // surface-area builder: per level one launch over the queue of open small nodes (a wave each) and, while nodes of more
+        // than SAH_BIG triangles can exist, one over the queue of big ones (a 1024-thread workgroup each); the queues are filled
+        // on the device, the launches are sized by what a level can hold at most and return at once beyond the queue's end
+        SahQueues q{};
+        const uint32_t cap_small = n_tris / (SAH_LEAF + 1u) + n_vaos, cap_big = n_tris / (SAH_BIG + 1u) + n_vaos;
+        q.levels = max_depth;
+        q.count = d_sah_nodes.as<uint32_t>();
+        {
+            char *base = reinterpret_cast<char *>(d_sah_nodes.ptr) + 256u * ((2u * (max_depth + 1u) * sizeof(uint32_t) + 255u) / 256u);
+            for (int par = 0; par < 2; par++) {
+                q.items[0][par] = reinterpret_cast<SahItem *>(base);
+                base += sizeof(SahItem) * (size_t)cap_small;
+            }
+            for (int par = 0; par < 2; par++) {
+                q.items[1][par] = reinterpret_cast<SahItem *>(base);
+                base += sizeof(SahItem) * (size_t)cap_big;
+            }
+        }
+        (void)hipMemsetAsync(d_sah_nodes.ptr, 0, 2u * (max_depth + 1u) * sizeof(uint32_t), st);
         hipLaunchKernelGGL(k_iota, dim3(tb), dim3(256), 0, st, d_vals[0].as<uint32_t>(), n_tris);
         hipLaunchKernelGGL(k_iota, dim3(tb), dim3(256), 0, st, d_fin.as<uint32_t>(), n_tris);
-        hipLaunchKernelGGL(k_sah_init, dim3((n_vaos + 255) / 256), dim3(256), 0, st, d_blas.as<BlasInfo>(), n_vaos, d_sah_nodes.as<SahNode>());
+        hipLaunchKernelGGL(k_sah_init, dim3((n_vaos + 255) / 256), dim3(256), 0, st, d_blas.as<BlasInfo>(), n_vaos, d_prim_cbounds.as<int>(), q);
         hipLaunchKernelGGL(k_tiny_roots<T>, dim3((n_vaos + 255) / 256), dim3(256), 0, st, d_blas.as<BlasInfo>(), n_vaos, d_tri_bounds.as<float>(),
                            d_roots.as<T>());
-        constexpr uint32_t BIG = 1024u; // nodes above this take a 1024-thread workgroup each, the others a wave
         for (uint32_t d = 0; d < max_depth; d++) {
-            const uint32_t nodes_d = n_vaos << d;
+            const uint64_t level_nodes = (uint64_t)n_vaos << std::min(d, 40u);
+            const uint32_t n_small = (uint32_t)std::min<uint64_t>(level_nodes, cap_small), n_big = (uint32_t)std::min<uint64_t>(level_nodes, cap_big);
             // a node at depth d holds at most SAH_LEAF << (D - d) triangles: below that, no node of this level is a big one
-            if ((SAH_LEAF << (max_depth - d)) > BIG)
-                hipLaunchKernelGGL((k_sah_level<T, 16u>), dim3(nodes_d), dim3(1024), 0, st, d_blas.as<BlasInfo>(), n_vaos, d, BIG, 0xffffffffu,
-                                   d_sah_nodes.as<SahNode>(), d_vals[d & 1u].as<uint32_t>(), d_vals[(d & 1u) ^ 1u].as<uint32_t>(), d_fin.as<uint32_t>(),
-                                   d_tri_bounds.as<float>(), d_inner.as<BlasNode<T>>(), d_roots.as<T>());
-            hipLaunchKernelGGL((k_sah_level<T, 1u>), dim3((nodes_d + 3u) / 4u), dim3(256), 0, st, d_blas.as<BlasInfo>(), n_vaos, d, SAH_LEAF, BIG,
-                               d_sah_nodes.as<SahNode>(), d_vals[d & 1u].as<uint32_t>(), d_vals[(d & 1u) ^ 1u].as<uint32_t>(), d_fin.as<uint32_t>(),
-                               d_tri_bounds.as<float>(), d_inner.as<BlasNode<T>>(), d_roots.as<T>());
+            if (((uint64_t)SAH_LEAF << (max_depth - d)) > SAH_BIG)
+                hipLaunchKernelGGL((k_sah_level<T, 16u>), dim3(n_big), dim3(1024), 0, st, d_blas.as<BlasInfo>(), d, q, d_vals[d & 1u].as<uint32_t>(),
+                                   d_vals[(d & 1u) ^ 1u].as<uint32_t>(), d_fin.as<uint32_t>(), d_tri_bounds.as<float>(), d_inner.as<BlasNode<T>>(),
+                                   d_roots.as<T>());
+            hipLaunchKernelGGL((k_sah_level<T, 1u>), dim3((n_small + 15u) / 16u), dim3(1024), 0, st, d_blas.as<BlasInfo>(), d, q, d_vals[d & 1u].as<uint32_t>(),
+                               d_vals[(d & 1u) ^ 1u].as<uint32_t>(), d_fin.as<uint32_t>(), d_tri_bounds.as<float>(), d_inner.as<BlasNode<T>>(),
+                               d_roots.as<T>());
         }
         hipLaunchKernelGGL(k_emit_triangles<T>, dim3(tb), dim3(256), 0, st, d_fin.as<uint32_t>(), d_mf32.as<TriRecF32>(), d_tri_bounds.as<float>(),
                            d_tri_prim.as<uint32_t>(), d_vaos.as<lprt_mesh_vao>(), n_tris, d_tris.as<TriRec<T>>(),

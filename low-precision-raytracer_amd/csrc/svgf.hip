@@ -218,7 +218,23 @@ __global__ void __launch_bounds__(256) k_temporal_color(FrameDev<T> fb, T color_
 // geometric part of a tap's weight, shared by both lobes: h * w_z * w_n is NOT pre-multiplied because the
 // reference multiplies w_z * w_n (* w_l) first and h last
 // w_n of a neighbour whose normal equals the centre's bit for bit is pow(max(0, dot(n_p, n_p)), 128): one value per pixel
-template <typename T> LPRT_DEV T normal_weight(V3<T> n_p, V3<T> n_q) { return cvt<T>(svgf_pow128((float)tmax((T)0, dot(n_p, n_q)))); }
+// a * b + c.  Half: two roundings, as the reference's float16 operators round (the half kernels reproduce the reference's
+// long-sequence behaviour pixel for pixel, tests/test_gpu_long_sequences.py).  Single precision: ONE rounding (v_fma_f32) --
+// the a-trous taps are bound by their vector instructions (~1,750 per pixel), the north star holds single-precision radiance
+// to 1e-3 relative L2 (the fused form moves it by ~1e-7), and a multiply-add per tap and channel is a third of the tap's
+// arithmetic.  -DLPRT_SVGF_NO_FMA restores the two-rounding form.
+template <typename T> LPRT_DEV T fmadd(T a, T b, T c) { return a * b + c; }
+#ifndef LPRT_SVGF_NO_FMA
+template <> LPRT_DEV float fmadd<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+#endif
+template <typename T> LPRT_DEV T dot_fm(V3<T> a, V3<T> b) { // dot_product (matrix.hpp:805-812): zero, then left to right
+    T s = (T)0;
+    s = fmadd(a.x, b.x, s);
+    s = fmadd(a.y, b.y, s);
+    s = fmadd(a.z, b.z, s);
+    return s;
+}
+template <typename T> LPRT_DEV T normal_weight(V3<T> n_p, V3<T> n_q) { return cvt<T>(svgf_pow128((float)tmax((T)0, dot_fm(n_p, n_q)))); }
 template <typename T>
 LPRT_DEV void geo_weights(T depth_p, T depth_q, V2<T> grad, T dx, T dy, V3<T> n_p, V3<T> n_q, T &w_z, T &w_n, T w_nn, bool flat_ok) {
     // exp(-abs(dz) / (SIGMA_Z * abs(dot(grad, dp) + EPS))): the unary minus makes the quotient a float.
@@ -395,8 +411,8 @@ __global__ void __launch_bounds__(WV_BX * WvRows<T>::value) k_wavelet(FrameDev<T
                 continue;
             T g = gk[i < 0 ? -i : i] * gk[j < 0 ? -j : j];
             uint32_t q = (uint32_t)(qy * W + qx);
-            sg[0] = sg[0] + g * vin0[q];
-            sg[1] = sg[1] + g * vin1[q];
+            sg[0] = fmadd(g, vin0[q], sg[0]);
+            sg[1] = fmadd(g, vin1[q], sg[1]);
             gw = gw + g;
         }
     }
@@ -496,11 +512,11 @@ __global__ void __launch_bounds__(WV_BX * WvRows<T>::value) k_wavelet(FrameDev<T
                     if (tfinite(hw)) {
                         const V4<T> cq = LDS_COLOR ? (l == 0 ? s_c0[ly][lx] : s_c1[ly][lx]) : in[l][(uint32_t)(qy * W + qx)];
                         if (tfinite(cq.w)) {
-                            nvar[l] = nvar[l] + hw * hw * cq.w;
+                            nvar[l] = fmadd(hw * hw, cq.w, nvar[l]);
                             wv[l] = wv[l] + hw;
                         }
                         if (tfinite(cq.x) && tfinite(cq.y) && tfinite(cq.z)) {
-                            ncol[l] = ncol[l] + hw * xyz(cq);
+                            ncol[l] = mk3(fmadd(hw, cq.x, ncol[l].x), fmadd(hw, cq.y, ncol[l].y), fmadd(hw, cq.z, ncol[l].z));
                             wc[l] = wc[l] + hw;
                         }
                     }

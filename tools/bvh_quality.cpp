@@ -72,6 +72,7 @@ struct Blas {
     double sah = 0;
 };
 
+static int g_variant = 0; // bit 0: longest centroid axis only; bit 1: bins over the node's box instead of the centroid bounds
 struct Params {
     int mode;  // 0 median, 1 sah
     int L;     // max triangles per leaf (sah)
@@ -107,7 +108,16 @@ static int build_rec(Blas &b, std::vector<Tri> &t, int l, int r, int d, int D, c
         double best = 1e300;
         int best_axis = -1, best_bin = -1;
         const int NB = pm.bins;
+        int longest = 0;
+        {
+            float w[3] = {cbx.hi[0] - cbx.lo[0], cbx.hi[1] - cbx.lo[1], cbx.hi[2] - cbx.lo[2]};
+            longest = (w[1] > w[0] && w[1] > w[2]) ? 1 : (w[2] > w[0] && w[2] > w[1]) ? 2 : 0;
+        }
+        if (g_variant & 2)
+            cbx = nb;
         for (int ax = 0; ax < 3; ax++) {
+            if ((g_variant & 1) && ax != longest)
+                continue;
             const float lo = cbx.lo[ax], ext = cbx.hi[ax] - lo;
             if (!(ext > 0))
                 continue;
@@ -334,7 +344,9 @@ int main(int argc, char **argv) {
             prims[p].push_back(t);
         }
     }
-    std::vector<Params> cfgs = {{0, 2, 0, 0}, {2, 2, 0, 32}, {2, 2, 0, 128}, {1, 2, 1, 32}, {1, 2, 3, 32}, {1, 4, 2, 32}, {1, 4, 4, 32}, {1, 4, 8, 32}, {1, 4, 4, 16}, {1, 8, 4, 32}, {1, 1, 4, 32}};
+    if (argc > 2)
+        g_variant = atoi(argv[2]);
+    std::vector<Params> cfgs = {{1, 2, 1, 16}};
     const int W = 256, H = 144;
     for (const Params &pm : cfgs) {
         std::vector<Blas> bl(np);

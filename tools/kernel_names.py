@@ -17,13 +17,20 @@ def short(name):
         n = int(m.group(1))
         k = name[m.end():m.end() + n]
         targs = name[m.end() + n:]
+        variant = ""
+        if k in ("fastslab", "refslab"):  # the ray-casting kernels live in a namespace per slab variant (csrc/kernels.hpp)
+            variant = "{refslab}" if k == "refslab" else ""
+            m2 = re.match(r"(\d+)", targs)
+            n = int(m2.group(1))
+            k = targs[m2.end():m2.end() + n]
+            targs = targs[m2.end() + n:]
         prec = "f16" if targs.startswith("IDF16_") else "f32"
         head = targs.split("EEv")[0]
         ints = re.findall(r"Li(\d+)E", head)
         bools = re.findall(r"Lb([01])E", head)
         count = "+count" if k in COUNTED and bools and count_flag(k, bools) == "1" else ""
-        return f"{k}{count}{'<' + ','.join(ints) + '>' if ints else ''}[{prec}]"
-    m = re.match(r"(?:lprt::)?(k_\w+)<(.*)>\(", name)
+        return f"{k}{count}{'<' + ','.join(ints) + '>' if ints else ''}[{prec}]{variant}"
+    m = re.match(r"(?:lprt::)?(?:fastslab::|refslab::)?(k_\w+)<(.*)>\(", name)
     if not m:
         return name.split("(")[0][:60]
     k, targs = m.group(1), m.group(2)
