@@ -22,7 +22,8 @@ class LprtError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "csrc", "liblprt_hip.so")
+    # LPRT_LIBRARY: another build of the same sources (A/B runs of compile-time knobs, tools/build_variant.sh)
+    return os.environ.get("LPRT_LIBRARY") or os.path.join(_HERE, "csrc", "liblprt_hip.so")
 
 
 # every symbol include/lprt.h declares: (name, restype, argtypes)

@@ -5,7 +5,7 @@
 TAG=$1; shift
 mkdir -p gpurun_out
 for V in "$@"; do
-  OUT="gpurun_out/ab_${TAG}_$(echo "$V" | tr ' =' '__').json"
+  OUT="gpurun_out/ab_${TAG}_$(echo "$V" | tr ' =/' '___' | tail -c 60).json"
   env $V python3 bench.py --no-cpu-baseline --steps 10 --warmup 2 --sustain-seconds 0 > "$OUT" 2> "$OUT.err" || { echo "FAILED: $V"; tail -5 "$OUT.err"; continue; }
   python3 - "$OUT" "$V" <<'PY'
 import json, sys
