@@ -263,6 +263,89 @@ def test_blas_is_a_valid_hierarchy(sponza, builder):
         assert max(leaf_depths) <= D and (builder == "sah" or min(leaf_depths) == D)
 
 
+def pathological_scene(seed=5):
+    """Meshes that take the corners of the surface-area builder (build.hip::k_sah_level): every triangle the same (coincident
+    centroids: no admissible plane, the object median by position); triangles strung along one axis (two of three axes
+    without extent); sizes at the seams between the code paths -- 4 and 5 (the smallest trees with records), 7, 64 / 65 (one
+    wave's worth), 256 / 257 (wave-per-node vs workgroup-per-node), 1025, 4100 (one-axis binning); a mesh with degenerate
+    (zero-area) and duplicated triangles; a huge triangle among small ones (the capacity rule excludes lopsided planes)."""
+    from lprt_amd.scenes import Mesh, assemble, translate
+    rng = np.random.default_rng(seed)
+
+    def mesh_from(tri):
+        tri = np.asarray(tri, dtype=np.float64)
+        nt = len(tri)
+        nrm = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+        ln = np.linalg.norm(nrm, axis=1, keepdims=True)
+        nrm = np.where(ln > 0, nrm / np.maximum(ln, 1e-30), np.array([[0.0, 1.0, 0.0]]))
+        return Mesh(tri.reshape(-1, 3), np.repeat(nrm, 3, axis=0), np.arange(3 * nt, dtype=np.uint32))
+
+    def soup(nt, spread=1.0, size=0.2):
+        return rng.uniform(-spread, spread, size=(nt, 1, 3)) + rng.normal(scale=size, size=(nt, 3, 3))
+
+    one = np.array([[0.0, 0.0, 0.0], [0.5, 0.0, 0.1], [0.1, 0.6, 0.0]])
+    meshes = [mesh_from(np.repeat(one[None], 37, axis=0)),                                            # 0: 37 identical triangles
+              mesh_from(np.stack([one * 0.05 + np.array([0.13 * k, 0.0, 0.0]) for k in range(70)])),   # 1: a string along x
+              mesh_from(soup(4)), mesh_from(soup(5)), mesh_from(soup(7)), mesh_from(soup(64)), mesh_from(soup(65)),
+              mesh_from(soup(256)), mesh_from(soup(257)), mesh_from(soup(1025, 1.5, 0.08)), mesh_from(soup(4100, 2.0, 0.05))]
+    weird = soup(90)
+    weird[10:20, 2] = weird[10:20, 1]          # zero-area triangles
+    weird[30:40] = weird[50:60]                 # duplicates
+    weird[0] = np.array([[-3.0, -3.0, 0.3], [3.0, -3.0, 0.3], [0.0, 3.0, 0.3]])  # one huge triangle
+    meshes.append(mesh_from(weird))
+    materials = [dict(color=(0.7, 0.7, 0.7), metallic=0.0, roughness=1.0, double_sided=True)]
+    instances = [(i, 0, translate((4.5 * (i % 4) - 6.0, 4.5 * (i // 4) - 4.0, 0.0))) for i in range(len(meshes))]
+    lights = [dict(type=abi.LIGHT_POINT, position=(0.0, 0.0, 9.0), intensity=(50.0, 50.0, 50.0))]
+    return assemble("pathological", meshes, materials, instances, lights, cam_eye=(0.0, 0.0, 16.0), cam_target=(0, 0, 0), fovy=0.9)
+
+
+@pytest.mark.parametrize("prec", [abi.F32, abi.F16])
+def test_surface_area_builder_on_pathological_meshes(prec):
+    """Every corner of k_sah_level (pathological_scene) at hit-record level: the trees are valid hierarchies over all the
+    triangles and cast_ray reports what the oracle reports (single precision: exactly, ties excepted; half precision:
+    disputed hits adjudicated by exhaustive search), closest-hit and any-hit, one- and two-level walk."""
+    INNER = 0xFFFFFFFF
+    sc = pathological_scene()
+    rays = random_rays(sc, 30000, 21, 1e-4 if prec == abi.F32 else 0.1)
+    with Oracle(16, 16, prec) as o:
+        o.load_scene(sc)
+        ho, hoa = o.trace(rays, False), o.trace(rays, True)
+        for wide in (0, 1):
+            with lprt_amd.Renderer(16, 16, prec) as r:
+                r.set_option("blas_builder", 2)
+                r.set_option("wide_walk", wide)
+                r.load_scene(sc)
+                if not wide:
+                    for vao in range(len(sc.vaos)):
+                        info = r.blas_info(vao)
+                        n, D = info["n_tris"], info["depth"]
+                        assert D == int(np.ceil(np.log2(np.ceil(n / 2)))) + 1
+                        root, boxes, words = r.blas_nodes(vao)
+                        seen = np.zeros(n, dtype=np.int32)
+                        stack = [(1, 0)]
+                        while stack:
+                            i, d = stack.pop()
+                            assert d < D
+                            for k in (0, 1):
+                                w = int(words[i - 1, k])
+                                if w == INNER:
+                                    stack.append((2 * i + k, d + 1))
+                                else:
+                                    assert 1 <= (w & 7) <= 2
+                                    seen[w >> 3:(w >> 3) + (w & 7)] += 1
+                        assert (seen == 1).all(), vao
+                hg, hga = r.trace(rays, False), r.trace(rays, True)
+            if prec == abi.F32:
+                compare_hits(ho, hg, False, 0.05)   # (37 coincident triangles: every hit of that mesh is a tie)
+                compare_hits(hoa, hga, True, 0.0)
+            else:
+                d = replay.closest_differs(hg, ho)
+                assert d.mean() < 0.02
+                j = replay.adjudicate(o, rays[d], hg[d], ho[d])
+                assert int((~j["gpu_nearest"] & j["oracle_nearest"]).sum()) <= max(3, int((j["gpu_nearest"] & ~j["oracle_nearest"]).sum()))
+                assert (hga["hit"] != hoa["hit"]).mean() < 5e-3
+
+
 def test_ragged_and_tiny_primitives():
     """1-, 2- and 3-triangle primitives (depth-0/1 trees) and an instance placed twice."""
     sc = scenes.small_test_scene(seed=99, n_objects=6)

@@ -346,12 +346,19 @@ int main(int argc, char **argv) {
     }
     if (argc > 2)
         g_variant = atoi(argv[2]);
-    std::vector<Params> cfgs = {{1, 2, 1, 16}};
+    if (argc > 3 && atoi(argv[3]) == 1) { // one BLAS over all primitives (identity instances merged)
+        std::vector<Tri> all;
+        for (auto &pr : prims)
+            all.insert(all.end(), pr.begin(), pr.end());
+        prims.assign(1, all);
+    }
+    const int np2 = (int)prims.size();
+    std::vector<Params> cfgs = {{0, 2, 0, 0}, {1, 2, 1, 16}};
     const int W = 256, H = 144;
     for (const Params &pm : cfgs) {
-        std::vector<Blas> bl(np);
+        std::vector<Blas> bl(np2);
 #pragma omp parallel for schedule(dynamic, 1)
-        for (int p = 0; p < np; p++)
+        for (int p = 0; p < np2; p++)
             bl[p] = build(prims[p], pm);
         int maxd = 0;
         double nodes = 0;
@@ -362,7 +369,7 @@ int main(int argc, char **argv) {
         auto cast = [&](V3 o, V3 d, float mn, float mx, bool any, Stats &st) {
             Hit h;
             st.rays++;
-            for (int p = 0; p < np; p++) {
+            for (int p = 0; p < np2; p++) {
                 walk(bl[p], p, o, d, mn, mx, any, h, st);
                 if (any && h.prim >= 0)
                     break;
