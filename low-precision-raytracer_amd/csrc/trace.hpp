@@ -145,6 +145,44 @@ template <bool SCENE> LPRT_DEV bool slab_test_reference_half(const h16 *lo, cons
 }
 #endif
 
+// min / max of the slab parameters.  Half instantiation: the parameters come out of v_fma_mix_f32 / v_pk_fma_f32, which LLVM does
+// not know to produce canonical values, so every operand of a __builtin_fminf / fmaxf got a `v_max_f32 x, x, x` in front of
+// it -- six per box test, a quarter of its vector instructions, in kernels whose time is their vector-instruction count
+// (DESIGN.md 9).  The hardware instructions themselves already ARE minnum / maxnum for everything arithmetic can produce
+// (a quiet NaN operand yields the other one; signalling NaNs do not come out of arithmetic), so the half instantiation
+// names them directly.  Single precision keeps the builtins (its parameters come from v_sub / v_mul: known canonical, and
+// the compiler may fold modifiers into them).
+template <typename T> struct SlabOps {
+    static LPRT_DEV float mn(float a, float b) { return __builtin_fminf(a, b); }
+    static LPRT_DEV float mx(float a, float b) { return __builtin_fmaxf(a, b); }
+    static LPRT_DEV float mx3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+    static LPRT_DEV float mn3(float a, float b, float c) { return __builtin_fminf(__builtin_fminf(a, b), c); }
+};
+#ifndef LPRT_NO_HW_MINMAX
+template <> struct SlabOps<h16> {
+    static LPRT_DEV float mn(float a, float b) {
+        float r;
+        asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+    }
+    static LPRT_DEV float mx(float a, float b) {
+        float r;
+        asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+    }
+    static LPRT_DEV float mx3(float a, float b, float c) {
+        float r;
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+        return r;
+    }
+    static LPRT_DEV float mn3(float a, float b, float c) {
+        float r;
+        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+        return r;
+    }
+};
+#endif
+
 // All six parameters finite (every ray that moves along all three axes: a product with a finite reciprocal can overflow to
 // +-inf, consistently signed, but never to NaN): entry = max3(min, min, min), exit = min3(max, max, max).
 template <typename T, bool SCENE> LPRT_DEV bool slab_test_moving(const T *lo, const T *hi, const RaySlab<T> &rs, float &tmn, float &tmx) {
@@ -155,8 +193,9 @@ template <typename T, bool SCENE> LPRT_DEV bool slab_test_moving(const T *lo, co
     const float a0 = slab_t(lo[0], rs.o.x, rs.ix), b0 = slab_t(hi[0], rs.o.x, rs.ix);
     const float a1 = slab_t(lo[1], rs.o.y, rs.iy), b1 = slab_t(hi[1], rs.o.y, rs.iy);
     const float a2 = slab_t(lo[2], rs.o.z, rs.iz), b2 = slab_t(hi[2], rs.o.z, rs.iz);
-    const float t1max = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a0, b0), __builtin_fminf(a1, b1)), __builtin_fminf(a2, b2));
-    const float t2min = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a0, b0), __builtin_fmaxf(a1, b1)), __builtin_fmaxf(a2, b2));
+    typedef SlabOps<T> O;
+    const float t1max = O::mx3(O::mn(a0, b0), O::mn(a1, b1), O::mn(a2, b2));
+    const float t2min = O::mn3(O::mx(a0, b0), O::mx(a1, b1), O::mx(a2, b2));
     tmn = t1max;
     tmx = t2min;
     if (SCENE) {
