@@ -1268,6 +1268,8 @@ template <typename T> void GeometryStore<T>::set_layout(hipStream_t st, int kind
                 lg++;
             bi.depth = lg + 1u;
         }
+        if (bi.depth > 28u) // the walks keep one pending bit per level in 32 bits (two-level walk: 4 bits per 2 levels in 64)
+            throw std::string("a primitive with more than 2^28 triangles is not supported");
         bi.inner_base = inner_total;
         bi.leaf_base = leaf_total;
         if (bi.n_tris) {

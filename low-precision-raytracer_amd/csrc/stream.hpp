@@ -19,20 +19,25 @@
 // kernels, bit for bit except exact-t ties, and against the oracle).
 #pragma once
 #include "trace.hpp"
+#include <type_traits>
 
 namespace lprt {
 
 
 // box test of the walk: trace.hpp's slab test + culls, the stationary-axis rejection as a run-time (wave-skipped) branch
 template <typename T>
-LPRT_DEV bool stream_box(const T *lo, const T *hi, const RaySlab<T> &rs, float best_t, float min_d, float max_d, float &tnear) {
+LPRT_DEV bool stream_box(const T *lo, const T *hi, const RaySlab<T> &rs, float best_t, float min_d, float max_d, float &tnear, bool wave_slow) {
     float x;
     bool h;
-    if (__builtin_amdgcn_ballot_w64(rs.slow != 0u)) { // rare: some lane's ray does not move along an axis (see trace.hpp)
+    if (wave_slow) { // rare: some lane's ray does not move along an axis (see trace.hpp); wave-uniform, evaluated once per node loop
         h = rs.slow ? slab_test_general<T, false>(lo, hi, rs, tnear, x) : slab_test_moving<T, false>(lo, hi, rs, tnear, x);
-    } else {
-        h = slab_test_moving<T, false>(lo, hi, rs, tnear, x);
+        return h && tnear < best_t && tnear < max_d && x > min_d;
     }
+#ifndef LPRT_REFSLAB_TU
+    if (Num<T>::is_half)
+        return box_hit_moving<T>(lo, hi, rs, SlabOps<T>::mn(best_t, max_d), cull_floor(min_d), tnear); // the culls folded in (trace.hpp)
+#endif
+    h = slab_test_moving<T, false>(lo, hi, rs, tnear, x);
     return h && tnear < best_t && tnear < max_d && x > min_d;
 }
 
@@ -97,7 +102,10 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items_all
     // (types.hpp: BlasNode -- leaves arrive with their parent's record and are never deferred); pend: deferred inner siblings
     uint32_t i = 1, c = 0, lf = 0, lf2 = 0; // (lf2: the second child record's leaves in the two-level walk)
     bool node_live = false;
-    unsigned long long pend = 0;
+    // (one bit per level in the one-level walk: 32 bits hold every tree the builders make -- depth <= 31 --; the two-level walk
+    // keeps four bits per two levels and needs 64)
+    typedef typename std::conditional<WIDE, unsigned long long, uint32_t>::type pend_t;
+    pend_t pend = 0;
     Isect<T> is;
     is.hit = false;
     is.t = (T)0;
@@ -152,17 +160,17 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items_all
                         // every world box against the ray (the boxes are wave-uniform addresses: scalar loads)
                         for (uint32_t k = 0; k < sc.n_objects; k++) {
                             const ObjRec<T> *ob = sc.objrecs + k;
-                            float a, b;
+                            float a;
                             if (COUNT)
                                 cnt.aabbw++;
-                            if (slab_test_scene(ob->lo, ob->hi, nrs, a, b) && a < (float)pr.tmax && b > (float)pr.tmin)
+                            if (scene_box(ob->lo, ob->hi, nrs, (float)pr.tmin, (float)pr.tmax, scene_floor((float)pr.tmin), a))
                                 pr.cand |= 1u << k;
                         }
                     } else {
-                        float a, b;
+                        float a;
                         if (COUNT)
                             cnt.tlas_nodes++;
-                        pr.cand = (slab_test_scene(sc.tlas_root, sc.tlas_root + 3, nrs, a, b) && a < (float)pr.tmax && b > (float)pr.tmin) ? 1u : 0u;
+                        pr.cand = scene_box(sc.tlas_root, sc.tlas_root + 3, nrs, (float)pr.tmin, (float)pr.tmax, scene_floor((float)pr.tmin), a) ? 1u : 0u;
                     }
                 }
             }
@@ -262,9 +270,9 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items_all
                             const InnerNode<T> nd = sc.tlas_inner[ti - 1];
                             if (COUNT)
                                 cnt.tlas_nodes += 2;
-                            float n0, x0, n1, x1;
-                            const bool h0 = slab_test_scene(nd.lo0, nd.hi0, wrs, n0, x0) && n0 < (float)tmax && x0 > (float)tmin;
-                            const bool h1 = slab_test_scene(nd.lo1, nd.hi1, wrs, n1, x1) && n1 < (float)tmax && x1 > (float)tmin;
+                            float n0, n1;
+                            const bool h0 = scene_box(nd.lo0, nd.hi0, wrs, (float)tmin, (float)tmax, scene_floor((float)tmin), n0);
+                            const bool h1 = scene_box(nd.lo1, nd.hi1, wrs, (float)tmin, (float)tmax, scene_floor((float)tmin), n1);
                             if (h0 | h1) {
                                 const uint32_t first = (h0 && (!h1 || n0 <= n1)) ? 0u : 1u;
                                 if (h0 & h1)
@@ -281,10 +289,10 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items_all
                                 const uint32_t s = first + tleaf;
                                 tleaf++;
                                 const ObjRec<T> *ob = sc.objrecs + s;
-                                float a, b;
+                                float a;
                                 if (COUNT)
                                     cnt.aabbw++;
-                                if (slab_test_scene(ob->lo, ob->hi, wrs, a, b) && a < (float)tmax && b > (float)tmin)
+                                if (scene_box(ob->lo, ob->hi, wrs, (float)tmin, (float)tmax, scene_floor((float)tmin), a))
                                     k = s;
                                 continue;
                             }
@@ -322,7 +330,7 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items_all
                     float tn;
                     if (COUNT)
                         cnt.blas_nodes++;
-                    if (stream_box(ob.root_lo, ob.root_hi, lrs, (float)is.t, (float)tmin, (float)tmax, tn)) {
+                    if (stream_box(ob.root_lo, ob.root_hi, lrs, (float)is.t, (float)tmin, (float)tmax, tn, __builtin_amdgcn_ballot_w64(lrs.slow != 0u) != 0ull)) {
                         inner = sc.blas_inner + ob.inner_base;
                         D = ob.depth;
                         n_tris = ob.n_tris;
@@ -354,19 +362,22 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items_all
             if (!pend)
                 return false;
             if (WIDE) {
-                const uint32_t bit = 63u - (uint32_t)__builtin_clzll(pend);
-                pend ^= 1ull << bit;
+                const uint32_t bit = 63u - (uint32_t)__builtin_clzll((unsigned long long)pend);
+                pend ^= (pend_t)(1ull << bit);
                 const uint32_t k2 = (bit >> 2) * 2u, j = bit & 3u; // depth of the node the step started from, grandchild slot
                 i = ((i >> (c - k2)) << 2) | j;
                 c = k2 + 2u;
             } else {
-                const uint32_t d = 63u - (uint32_t)__builtin_clzll(pend);
-                pend ^= 1ull << d;
+                const uint32_t d = 31u - (uint32_t)__builtin_clz((uint32_t)pend);
+                pend ^= (pend_t)1u << d;
                 i = (i >> (c - d)) ^ 1u;
                 c = d;
             }
             return true;
         };
+        // (a lane changes its ray only in the entry phase: whether some lane of the wave holds a ray with a stationary axis is
+        // invariant across the node loop)
+        const bool wave_slow = __builtin_amdgcn_ballot_w64(in_obj && lrs.slow != 0u) != 0ull;
         while (run_node && in_obj && node_live && (lf | lf2) == 0u) {
             cnt.step(1);
             if (WIDE && c + 2u <= D) {
@@ -376,8 +387,8 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items_all
                     cnt.blas_nodes += 4;
                 float n[4];
                 const float bt = (float)is.t, mn = (float)tmin, mx = (float)tmax;
-                const bool h0 = stream_box(ra.lo0, ra.hi0, lrs, bt, mn, mx, n[0]), h1 = stream_box(ra.lo1, ra.hi1, lrs, bt, mn, mx, n[1]);
-                const bool h2 = stream_box(rb.lo0, rb.hi0, lrs, bt, mn, mx, n[2]), h3 = stream_box(rb.lo1, rb.hi1, lrs, bt, mn, mx, n[3]);
+                const bool h0 = stream_box(ra.lo0, ra.hi0, lrs, bt, mn, mx, n[0], wave_slow), h1 = stream_box(ra.lo1, ra.hi1, lrs, bt, mn, mx, n[1], wave_slow);
+                const bool h2 = stream_box(rb.lo0, rb.hi0, lrs, bt, mn, mx, n[2], wave_slow), h3 = stream_box(rb.lo1, rb.hi1, lrs, bt, mn, mx, n[3], wave_slow);
                 const bool l0 = ra.leaf[0] != LPRT_CHILD_INNER, l1 = ra.leaf[1] != LPRT_CHILD_INNER;
                 const bool l2 = rb.leaf[0] != LPRT_CHILD_INNER, l3 = rb.leaf[1] != LPRT_CHILD_INNER;
                 if (h0 && l0)
@@ -400,7 +411,7 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items_all
                             first = q;
                             have = true;
                         }
-                    pend |= (unsigned long long)(g & ~(1u << first)) << (2 * c);
+                    pend |= (pend_t)((unsigned long long)(g & ~(1u << first)) << (2 * c));
                     i = 4 * i + first;
                     c += 2;
                 } else {
@@ -412,8 +423,8 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items_all
                     cnt.blas_nodes += 2;
                 float n0, n1;
                 const float bt = (float)is.t, mn = (float)tmin, mx = (float)tmax;
-                const bool h0 = stream_box(nd.lo0, nd.hi0, lrs, bt, mn, mx, n0);
-                const bool h1 = stream_box(nd.lo1, nd.hi1, lrs, bt, mn, mx, n1);
+                const bool h0 = stream_box(nd.lo0, nd.hi0, lrs, bt, mn, mx, n0, wave_slow);
+                const bool h1 = stream_box(nd.lo1, nd.hi1, lrs, bt, mn, mx, n1, wave_slow);
                 const bool l0 = nd.leaf[0] != LPRT_CHILD_INNER, l1 = nd.leaf[1] != LPRT_CHILD_INNER;
                 if (h0 && l0)
                     lf = nd.leaf[0];
@@ -423,7 +434,7 @@ LPRT_DEV void trace_stream(const SceneDev<T> &sc, Src &src, uint32_t n_items_all
                 if (g0 | g1) {
                     const uint32_t first = (g0 && (!g1 || n0 <= n1)) ? 0u : 1u;
                     if (g0 & g1)
-                        pend |= 1ull << (c + 1);
+                        pend |= (pend_t)1u << (c + 1);
                     i = 2 * i + first;
                     c += 1;
                 } else {

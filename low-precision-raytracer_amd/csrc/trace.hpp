@@ -204,6 +204,23 @@ template <typename T, bool SCENE> LPRT_DEV bool slab_test_moving(const T *lo, co
     }
     return t1max <= t2min * 1.001953f && 0.0f <= t2min;
 }
+// The object-level box test with the walk's culls folded in, decision for decision:
+//     slab (entry <= exit * 1.001953  &&  0 <= exit)  &&  entry < best_t  &&  entry < max_d  &&  exit > min_d
+//  =  entry <= exit * 1.001953  &&  entry < tcull  &&  exit > mfloor,      tcull = min(best_t, max_d),
+//     mfloor = min_d if min_d >= 0, else the largest negative float (exit > mfloor <=> 0 <= exit; and exit > min_d >= 0 implies it)
+// -- three comparisons per box instead of five (the compiler cannot know the sign of min_d).
+LPRT_DEV float cull_floor(float min_d) { return min_d >= 0.0f ? min_d : -1.4e-45f; }
+template <typename T> LPRT_DEV bool box_hit_moving(const T *lo, const T *hi, const RaySlab<T> &rs, float tcull, float mfloor, float &tnear) {
+    const float a0 = slab_t(lo[0], rs.o.x, rs.ix), b0 = slab_t(hi[0], rs.o.x, rs.ix);
+    const float a1 = slab_t(lo[1], rs.o.y, rs.iy), b1 = slab_t(hi[1], rs.o.y, rs.iy);
+    const float a2 = slab_t(lo[2], rs.o.z, rs.iz), b2 = slab_t(hi[2], rs.o.z, rs.iz);
+    typedef SlabOps<T> O;
+    const float t1max = O::mx3(O::mn(a0, b0), O::mn(a1, b1), O::mn(a2, b2));
+    const float t2min = O::mn3(O::mx(a0, b0), O::mx(a1, b1), O::mx(a2, b2));
+    tnear = t1max;
+    return t1max <= t2min * 1.001953f && t1max < tcull && t2min > mfloor;
+}
+
 // General form: axes whose entry/exit is not finite are ignored (parallel rays), as in the reference; entry = max over the
 // remaining axes, exit = min (the reference's sequential update computes exactly these extrema).
 template <typename T, bool SCENE> LPRT_DEV bool slab_test_general(const T *lo, const T *hi, const RaySlab<T> &rs, float &tmn, float &tmx) {
@@ -242,11 +259,45 @@ template <typename T, bool SCENE, bool PAR = false> LPRT_DEV bool slab_test(cons
     return slab_test_moving<T, SCENE>(lo, hi, rs, tmn, tmx);
 }
 
+// a BLAS box against a ray inside traverse_blas: the folded test for rays that move along all axes, the general form otherwise
+template <typename T, bool PAR> LPRT_DEV bool blas_box(const T *lo, const T *hi, const RaySlab<T> &rs, float best_t, float min_d, float max_d, float &tnear) {
+#ifndef LPRT_REFSLAB_TU
+    // (half only: in the single-precision per-pixel kernels, which sit at their register budget, the folded form measured
+    // SLOWER -- Cornell k_trace_gi 0.647 -> 0.676 ms, primary rays 0.071 -> 0.092 -- while the half kernels gained 3-4 %)
+    if (!PAR && Num<T>::is_half)
+        return box_hit_moving<T>(lo, hi, rs, SlabOps<T>::mn(best_t, max_d), cull_floor(min_d), tnear);
+#endif
+    float x;
+    return slab_test<T, false, PAR>(lo, hi, rs, tnear, x) && tnear < best_t && tnear < max_d && x > min_d;
+}
+
 // world-box / TLAS-node test: one code path per ray kind, chosen at run time (the scene level is a few tests per ray)
 template <typename T> LPRT_DEV bool slab_test_scene(const T *lo, const T *hi, const RaySlab<T> &rs, float &tmn, float &tmx) {
     if (rs.slow)
         return slab_test_general<T, true>(lo, hi, rs, tmn, tmx);
     return slab_test_moving<T, true>(lo, hi, rs, tmn, tmx);
+}
+
+// The same fold for the scene-level test (slack + 0.02, no cull by the closest hit, cuda.hpp:98, 536-538):
+//     entry <= exit + 0.02  &&  0 <= exit + 0.02  &&  entry < max_d  &&  exit > min_d
+// `0 <= exit + 0.02f` is `exit >= -0.02f` exactly (the sum of two floats that close is exact), so with
+// sfloor = min_d if min_d >= -0.02f, else the float just below -0.02f, the last three comparisons are two.
+LPRT_DEV float scene_floor(float min_d) { return min_d >= -0.02f ? min_d : __builtin_bit_cast(float, 0xbca3d70bu); } // the float just below -0.02f (0xbca3d70a)
+template <typename T> LPRT_DEV bool scene_box(const T *lo, const T *hi, const RaySlab<T> &rs, float min_d, float max_d, float sfloor, float &tnear) {
+    float x;
+#ifndef LPRT_REFSLAB_TU
+    if (Num<T>::is_half && !rs.slow) { // (half only, as blas_box)
+        const float a0 = slab_t(lo[0], rs.o.x, rs.ix), b0 = slab_t(hi[0], rs.o.x, rs.ix);
+        const float a1 = slab_t(lo[1], rs.o.y, rs.iy), b1 = slab_t(hi[1], rs.o.y, rs.iy);
+        const float a2 = slab_t(lo[2], rs.o.z, rs.iz), b2 = slab_t(hi[2], rs.o.z, rs.iz);
+        typedef SlabOps<T> O;
+        const float t1max = O::mx3(O::mn(a0, b0), O::mn(a1, b1), O::mn(a2, b2));
+        const float t2min = O::mn3(O::mx(a0, b0), O::mx(a1, b1), O::mx(a2, b2));
+        tnear = t1max;
+        return t1max <= t2min + 0.02f && t1max < max_d && t2min > sfloor;
+    }
+#endif
+    return slab_test_scene(lo, hi, rs, tnear, x) && tnear < max_d && x > min_d;
 }
 
 template <bool COUNT> struct Cnt {
@@ -459,12 +510,12 @@ LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, const Ray
                     const BlasNode<T> ra = inner[2 * i - 1], rb = inner[2 * i];
                     if (COUNT)
                         cnt.blas_nodes += 4;
-                    float n[4], x;
+                    float n[4];
                     const float best_t = (float)is.t;
-                    const bool h0 = slab_test<T, false, PAR>(ra.lo0, ra.hi0, rs, n[0], x) && n[0] < best_t && n[0] < max_d && x > min_d;
-                    const bool h1 = slab_test<T, false, PAR>(ra.lo1, ra.hi1, rs, n[1], x) && n[1] < best_t && n[1] < max_d && x > min_d;
-                    const bool h2 = slab_test<T, false, PAR>(rb.lo0, rb.hi0, rs, n[2], x) && n[2] < best_t && n[2] < max_d && x > min_d;
-                    const bool h3 = slab_test<T, false, PAR>(rb.lo1, rb.hi1, rs, n[3], x) && n[3] < best_t && n[3] < max_d && x > min_d;
+                    const bool h0 = blas_box<T, PAR>(ra.lo0, ra.hi0, rs, best_t, min_d, max_d, n[0]);
+                    const bool h1 = blas_box<T, PAR>(ra.lo1, ra.hi1, rs, best_t, min_d, max_d, n[1]);
+                    const bool h2 = blas_box<T, PAR>(rb.lo0, rb.hi0, rs, best_t, min_d, max_d, n[2]);
+                    const bool h3 = blas_box<T, PAR>(rb.lo1, rb.hi1, rs, best_t, min_d, max_d, n[3]);
                     const bool l0 = ra.leaf[0] != LPRT_CHILD_INNER, l1 = ra.leaf[1] != LPRT_CHILD_INNER;
                     const bool l2 = rb.leaf[0] != LPRT_CHILD_INNER, l3 = rb.leaf[1] != LPRT_CHILD_INNER;
                     if (h0 && l0)
@@ -494,10 +545,10 @@ LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, const Ray
                     const BlasNode<T> nd = inner[i - 1];
                     if (COUNT)
                         cnt.blas_nodes += 2;
-                    float n0, x0, n1, x1;
+                    float n0, n1;
                     const float best_t = (float)is.t;
-                    const bool h0 = slab_test<T, false, PAR>(nd.lo0, nd.hi0, rs, n0, x0) && n0 < best_t && n0 < max_d && x0 > min_d;
-                    const bool h1 = slab_test<T, false, PAR>(nd.lo1, nd.hi1, rs, n1, x1) && n1 < best_t && n1 < max_d && x1 > min_d;
+                    const bool h0 = blas_box<T, PAR>(nd.lo0, nd.hi0, rs, best_t, min_d, max_d, n0);
+                    const bool h1 = blas_box<T, PAR>(nd.lo1, nd.hi1, rs, best_t, min_d, max_d, n1);
                     if (h0 && nd.leaf[0] != LPRT_CHILD_INNER)
                         lfa = nd.leaf[0];
                     if (h1 && nd.leaf[1] != LPRT_CHILD_INNER)
@@ -548,10 +599,10 @@ LPRT_DEV void traverse_blas(const SceneDev<T> &sc, const RayT<T> &ray, const Ray
             if (COUNT)
                 cnt.blas_nodes += 2;
             cnt.step(1);
-            float n0, x0, n1, x1;
+            float n0, n1;
             const float best_t = (float)is.t;
-            const bool h0 = slab_test<T, false, PAR>(nd.lo0, nd.hi0, rs, n0, x0) && n0 < best_t && n0 < max_d && x0 > min_d;
-            const bool h1 = slab_test<T, false, PAR>(nd.lo1, nd.hi1, rs, n1, x1) && n1 < best_t && n1 < max_d && x1 > min_d;
+            const bool h0 = blas_box<T, PAR>(nd.lo0, nd.hi0, rs, best_t, min_d, max_d, n0);
+            const bool h1 = blas_box<T, PAR>(nd.lo1, nd.hi1, rs, best_t, min_d, max_d, n1);
             const bool l0 = nd.leaf[0] != LPRT_CHILD_INNER, l1 = nd.leaf[1] != LPRT_CHILD_INNER;
             if (h0 && l0)
                 lf = nd.leaf[0];
@@ -603,8 +654,8 @@ LPRT_DEV Isect<T> cast_ray(const SceneDev<T> &sc, const RayT<T> &ray, uint32_t s
     if (sc.n_objects == 0)
         return is;
     const RaySlab<T> rs = make_slab(ray, sc.axis_reject);
-    const float min_d = (float)min_distance, max_d = (float)max_distance;
-    float tmn, tmx;
+    const float min_d = (float)min_distance, max_d = (float)max_distance, sfloor = scene_floor(min_d);
+    float tmn;
     if (sc.tlas_mode == 1u) {
         // Small scenes (the Cornell box has 8 instances): a tree over a handful of mutually overlapping boxes costs ~2n
         // slab tests per ray; scan the n world boxes instead.  The scan loop is wave-uniform, so the boxes arrive through
@@ -614,7 +665,7 @@ LPRT_DEV Isect<T> cast_ray(const SceneDev<T> &sc, const RayT<T> &ray, uint32_t s
             const ObjRec<T> *ob = sc.objrecs + k;
             if (COUNT)
                 cnt.aabbw++;
-            if (slab_test_scene(ob->lo, ob->hi, rs, tmn, tmx) && tmn < max_d && tmx > min_d)
+            if (scene_box(ob->lo, ob->hi, rs, min_d, max_d, sfloor, tmn))
                 cand |= 1u << k;
         }
         while (cand) {
@@ -642,7 +693,7 @@ LPRT_DEV Isect<T> cast_ray(const SceneDev<T> &sc, const RayT<T> &ray, uint32_t s
     }
     if (COUNT)
         cnt.tlas_nodes++;
-    if (!(slab_test_scene(sc.tlas_root, sc.tlas_root + 3, rs, tmn, tmx) && tmn < max_d && tmx > min_d))
+    if (!scene_box(sc.tlas_root, sc.tlas_root + 3, rs, min_d, max_d, sfloor, tmn))
         return is;
     const uint32_t D = sc.tlas_depth;
     uint32_t i = 1, c = 0, pending = 0;
@@ -651,10 +702,10 @@ LPRT_DEV Isect<T> cast_ray(const SceneDev<T> &sc, const RayT<T> &ray, uint32_t s
             const InnerNode<T> nd = sc.tlas_inner[i - 1];
             if (COUNT)
                 cnt.tlas_nodes += 2;
-            float n0, x0, n1, x1;
+            float n0, n1;
             // no `tmin < intersection.t` cull at the scene level (cuda.hpp:536-538)
-            bool h0 = slab_test_scene(nd.lo0, nd.hi0, rs, n0, x0) && n0 < max_d && x0 > min_d;
-            bool h1 = slab_test_scene(nd.lo1, nd.hi1, rs, n1, x1) && n1 < max_d && x1 > min_d;
+            bool h0 = scene_box(nd.lo0, nd.hi0, rs, min_d, max_d, sfloor, n0);
+            bool h1 = scene_box(nd.lo1, nd.hi1, rs, min_d, max_d, sfloor, n1);
             if (h0 | h1) {
                 uint32_t first = (h0 && (!h1 || n0 <= n1)) ? 0u : 1u;
                 if (h0 & h1)
@@ -671,7 +722,7 @@ LPRT_DEV Isect<T> cast_ray(const SceneDev<T> &sc, const RayT<T> &ray, uint32_t s
                 const ObjRec<T> *ob = sc.objrecs + first + k;
                 if (COUNT)
                     cnt.aabbw++;
-                if (slab_test_scene(ob->lo, ob->hi, rs, tmn, tmx) && tmn < max_d && tmx > min_d) {
+                if (scene_box(ob->lo, ob->hi, rs, min_d, max_d, sfloor, tmn)) {
                     const ObjRec<T> obv = *ob;
                     RayT<T> lr = ray;
                     RaySlab<T> lrs = rs;
