@@ -64,24 +64,39 @@ def test_fp32_hit_records_match_oracle(scene_name, n, builder):
         compare_hits(o.trace(rays, any_hit), r.trace(rays, any_hit), any_hit, 0.01)
 
 
+@pytest.mark.parametrize("slab", [0, 1], ids=["f32-slab", "reference-slab"])
 @pytest.mark.parametrize("scene_name", ["cornell", "small_test"])
-def test_fp16_hit_records_match_oracle(scene_name):
-    """fp16: the GPU rounds boxes OUTWARD (DEVIATION Q2) where the reference rounds to nearest, so it may find hits the
-    reference's slab test loses; on these small-coordinate scenes every box coordinate is representable and the
-    results must still be identical."""
+def test_fp16_hit_records_match_oracle(scene_name, slab):
+    """Half-precision hit records on the small scenes, 60 k rays, both slab modes, held to what was measured in round 3
+    (tools/gpu_fp16_small_probe.py) instead of percentages:
+      * random soup (`small_test`): identical to the oracle -- flags, triangles, t, barycentrics, visibility -- in both modes;
+      * Cornell box, reference slab arithmetic: identical flags and visibility; ~50 rays report another triangle, every one an
+        exact-t tie between coplanar triangles of two instances (both answers are nearest hits by exhaustive search);
+      * Cornell box, default (f32) slab parameters: the same ties, plus at most a handful of rays where ONLY the GPU reports the
+        nearest hit (the reference's half slab test culled the box) and never the reverse."""
     sc = scenes.SCENES[scene_name]()
     o = Oracle(16, 16, abi.F16)
     o.load_scene(sc)
     r = lprt_amd.Renderer(16, 16, abi.F16)
+    r.set_option("reference_slab", slab)
     r.load_scene(sc)
     rays = random_rays(sc, 60000, 12, 0.1)
     ho, hg = o.trace(rays, False), r.trace(rays, False)
-    assert (ho["hit"] != hg["hit"]).mean() < 1e-3
-    both = (ho["hit"] == 1) & (hg["hit"] == 1)
-    same = both & (ho["inscene_objid"] == hg["inscene_objid"]) & (ho["inobject_offset"] == hg["inobject_offset"])
-    assert same.sum() >= 0.99 * both.sum()
-    assert np.array_equal(ho["t"][same], hg["t"][same])
-    assert (o.trace(rays, True)["hit"] != r.trace(rays, True)["hit"]).mean() < 1e-3
+    hoa, hga = o.trace(rays, True), r.trace(rays, True)
+    d = replay.closest_differs(hg, ho)
+    same = ~d & (ho["hit"] == 1)
+    assert np.array_equal(ho["t"][same], hg["t"][same]) and np.array_equal(ho["barycentric"][same], hg["barycentric"][same])
+    if scene_name == "small_test":
+        assert not d.any() and np.array_equal(hoa["hit"], hga["hit"])
+        return
+    j = replay.adjudicate(o, rays[d], hg[d], ho[d])
+    only_gpu, only_oracle = j["gpu_nearest"] & ~j["oracle_nearest"], ~j["gpu_nearest"] & j["oracle_nearest"]
+    assert int(d.sum()) <= 80 and not only_oracle.any() and (j["gpu_nearest"] | j["oracle_nearest"]).all()
+    flags, vis = int((ho["hit"] != hg["hit"]).sum()), int((hoa["hit"] != hga["hit"]).sum())
+    if slab:
+        assert flags == 0 and vis == 0 and not only_gpu.any()
+    else:
+        assert flags <= 3 and vis <= 3 and int(only_gpu.sum()) <= 6
 
 
 @pytest.mark.parametrize("slab", [0, 1], ids=["f32-slab", "reference-slab"])
@@ -178,8 +193,8 @@ def test_two_level_walk_reports_the_hits_of_the_one_level_walk(sponza, prec):
         ho = o.trace(rays, bool(any_hit))
         if prec == abi.F32:
             compare_hits(ho, b, bool(any_hit), 0.01)
-        else:
-            assert (ho["hit"] != b["hit"]).mean() < 0.02
+        else:  # (the half-precision statement proper: test_fp16_closest_hits_on_the_atrium_against_oracle_and_exhaustive_search)
+            assert (ho["hit"] != b["hit"]).mean() < 2e-3
 
 
 def test_golden_ray_batch(small_scene):
