@@ -4,8 +4,11 @@
 //    M_shift_f32 / M_shift and position_f32, computed on the device with the same
 //    DifferenceOfProducts cofactors (rt/math/matrix.hpp:407-427, 829-843).
 // B1 replaces ObjectBVH::build_object_bvh (rt/trace/object_bvh.hpp:49-134), a single-threaded CPU
-//    median split, by: Morton codes of triangle centroids -> own LSD radix sort (wave ballot ranking,
-//    no Thrust/rocPRIM) -> implicit perfect median tree over the sorted order -> bottom-up boxes.
+//    median split, by two GPU builders over one record format (types.hpp: BlasNode, implicit heap slots):
+//    a binned surface-area builder (k_sah_level: level by level from device queues, one wave or one
+//    workgroup per node, stable ballot partition, no refit) for primitives large enough to have a
+//    hierarchy, and the reference's rule -- object median along the widest axis -- level by level with an
+//    own LSD radix sort (wave ballot ranking, no Thrust/rocPRIM) and bottom-up boxes otherwise.
 // B2 replaces SceneBVH::update (rt/trace/scene_bvh.hpp:50-133), rebuilt per frame on the CPU, by a
 //    single-workgroup kernel (LDS bitonic sort + the same tree).
 #include "build.hpp"

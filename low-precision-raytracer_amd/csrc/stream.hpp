@@ -11,7 +11,7 @@
 // two-level steps), rewritten as a resumable per-lane state machine:
 //     fetch  ->  [ next candidate instance | TLAS step ]  ->  node steps (while-while)  ->  leaf triangles  ->  ...
 // Results go to planes (visibility byte per light slot, hit record per pixel); the per-pixel stages that used to follow in
-// the same thread (shade #2, accumulate + compose) run as streaming kernels of their own (stream.hip), at full lane use.
+// the same thread (shade #2, accumulate + compose) run as streaming kernels of their own (pipeline.hip: k_shade2, k_accum_di), at full lane use.
 //
 // Exit condition reached by every wave: the stream counter only grows; a wave leaves when a fetch found the stream
 // exhausted and none of its lanes holds a ray.  Replaces the launch structure of trace_gi / trace_di_light

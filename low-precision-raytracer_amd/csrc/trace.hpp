@@ -5,10 +5,10 @@
 // 415-631).  What is kept bit-for-bit is the ARITHMETIC that decides hits (slab tests with the same
 // slack constants, the precomputed-transform triangle test with its fp32 t and fp32 edge-zone re-test,
 // ray transform without renormalisation).  What is NOT kept is the reference's stackless
-// parent-pointer walk over 1-primitive leaves: traversal here runs over an implicit perfect tree with
-// child boxes stored in the parent, near-child-first, with a one-bit-per-level "pending sibling" mask
-// instead of a stack (no LDS, no scratch).  Closest-hit results are order independent except at exact
-// t ties.
+// parent-pointer walk over 1-primitive leaves: traversal here runs over an implicitly indexed tree (heap
+// slots, depth-bounded; types.hpp: BlasNode) with the boxes AND leaf words of both children stored in the
+// parent, near-child-first, with a one-bit-per-level "pending sibling" mask instead of a stack (no LDS, no
+// scratch).  Closest-hit results are order independent except at exact t ties.
 #pragma once
 #include "types.hpp"
 

@@ -29,8 +29,8 @@ struct alignas(16) TriRecF32 { // 48 B
 };
 
 // ---- acceleration structures -------------------------------------------------------------------
-// Perfect binary tree over Morton-sorted primitives, heap order (root = 1, children 2i / 2i+1), all
-// leaves at depth D = floor(log2 n); a leaf owns 1 or 2 consecutive sorted primitives.  An inner node
+// TLAS node: perfect binary tree over the Morton-sorted instances, heap order (root = 1, children 2i / 2i+1), all
+// leaves at depth D = floor(log2 n); a leaf owns 1 or 2 consecutive sorted instances (leaf-word array).  An inner node
 // stores the boxes of BOTH children, so one fetch feeds two slab tests.
 template <typename T> struct alignas(sizeof(T) * 4) InnerNode { // 48 B (f32) / 24 B (f16)
     T lo0[3], hi0[3], lo1[3], hi1[3];
