@@ -85,15 +85,23 @@ def closest_differs(hg, ho):
     return (hg["hit"] != ho["hit"]) | ((hg["hit"] == 1) & ((hg["inscene_objid"] != ho["inscene_objid"]) | (hg["inobject_offset"] != ho["inobject_offset"])))
 
 
-def _visibility_bits(x, rays, pix, npix):
-    """bit s of pixel p: the shadow ray of light slot s is blocked (own commands on own tracer)."""
-    vis = x.trace(rays, True)["hit"].astype(np.uint32)
-    # rays are concatenated slot by slot; recover the slot of each ray from the pixel order restarting
-    slot = np.zeros(len(rays), dtype=np.uint32)
+def _ray_slots(pix):
+    """rays are concatenated slot by slot; the slot of each ray = how often the pixel order has restarted before it"""
+    slot = np.zeros(len(pix), dtype=np.uint32)
     if len(pix):
         starts = np.flatnonzero(np.diff(pix.astype(np.int64)) < 0) + 1
         slot[starts] = 1
         slot = np.cumsum(slot).astype(np.uint32)
+    return slot
+
+
+def _visibility_bits(x, rays, pix, npix, keep=None):
+    """bit s of pixel p: the shadow ray of light slot s is blocked (own commands on own tracer).  keep: a list that receives
+    (rays, pixel * 4 + slot, blocked) for adjudicate_shadow()."""
+    vis = x.trace(rays, True)["hit"].astype(np.uint32)
+    slot = _ray_slots(pix)
+    if keep is not None:
+        keep.append((rays, pix.astype(np.int64) * 4 + slot, vis))
     bits = np.zeros(npix, dtype=np.uint32)
     np.bitwise_or.at(bits, pix, vis << slot)
     return bits
@@ -104,7 +112,7 @@ def _side(x, sc, prec, frame, spp, rebuild_blas):
     history is reset).  Per-sample stages depend on nothing but the G-buffer and the seeds, so a 1-spp frame with sample
     s's seeds casts sample s's rays; the planes it leaves behind are then read back and its own rays replayed through
     its own cast_ray."""
-    out = {"gi": [], "gi_rays": [], "gi_mask": [], "shadow1": [], "shadow1_mask": [], "n_rays": 0}
+    out = {"gi": [], "gi_rays": [], "gi_mask": [], "shadow1": [], "shadow1_mask": [], "n_rays": 0, "shadow_rays": []}
 
     def run(seeds, gi_on):
         fs = abi.default_settings(spp=1, gi_on=gi_on, svgf=False, seeds=seeds)
@@ -115,7 +123,7 @@ def _side(x, sc, prec, frame, spp, rebuild_blas):
 
     run(sample_seeds(frame, spp, 0), False)  # round 0: its commands depend on the G-buffer and the lights only
     rays, pix, (rows, W) = shadow_rays(x, prec, True)
-    out["shadow0"] = _visibility_bits(x, rays, pix, rows * W).reshape(rows, W)
+    out["shadow0"] = _visibility_bits(x, rays, pix, rows * W, out["shadow_rays"]).reshape(rows, W)
     out["shadow0_mask"] = x.read("LIGHT_MASK")[..., 0].astype(np.uint32)
     out["n_rays"] += len(rays)
     for s in range(spp):
@@ -130,7 +138,7 @@ def _side(x, sc, prec, frame, spp, rebuild_blas):
         out["gi_rays"].append(full)
         out["gi_mask"].append(mask)
         rays1, pix, _ = shadow_rays(x, prec, False)
-        out["shadow1"].append(_visibility_bits(x, rays1, pix, rows * W).reshape(rows, W))
+        out["shadow1"].append(_visibility_bits(x, rays1, pix, rows * W, out["shadow_rays"]).reshape(rows, W))
         out["shadow1_mask"].append(x.read("LIGHT_MASK")[..., 0].astype(np.uint32))
         out["n_rays"] += len(rays) + len(rays1)
     return out
@@ -207,6 +215,36 @@ def adjudicate_gi(c, o, kinds=("gi_cull", "gi_tie")):
         tot["gpu_lost"] += int((~gn & on).sum())
         tot["oracle_lost"] += int((gn & ~on).sum())
         tot["neither"] += int((~gn & ~on).sum())
+    return tot
+
+
+def adjudicate_shadow(c, o):
+    """The disputed SHADOW rays of a classified frame (round 0 and every sample's round 1): the same bit-identical ray on both
+    sides, blocked on one and not on the other.  "Blocked" is always right -- it names a triangle the reference's triangle
+    test accepts inside the ray's window -- so the side that reports the ray as free lost the blocker to a box cull; the
+    exhaustive search says which rays are blocked at all.  Returns counts: disputed, gpu_lost (the GPU reports a blocked ray
+    as free), oracle_lost, unexplained (the exhaustive search finds no blocker although one side reports one: impossible
+    unless a walk invents a hit)."""
+    g, cc = c["sides"]
+    tot = dict(disputed=0, gpu_lost=0, oracle_lost=0, unexplained=0)
+    for (rg, kg, vg), (ro, ko, vo) in zip(g["shadow_rays"], cc["shadow_rays"]):
+        common, ig, io = np.intersect1d(kg, ko, return_indices=True)
+        if not len(common):
+            continue
+        a, b = rg[ig], ro[io]
+        same = np.ones(len(common), dtype=bool)
+        for f in ("source", "direction", "max_distance"):
+            x, y = a[f].view(np.uint32), b[f].view(np.uint32)
+            same &= (x == y).reshape(len(common), -1).all(axis=1)
+        d = same & (vg[ig] != vo[io])
+        if not d.any():
+            continue
+        e = o.trace_exhaustive(a[d])["hit"]
+        gv, ov = vg[ig][d], vo[io][d]
+        tot["disputed"] += int(d.sum())
+        tot["gpu_lost"] += int(((gv == 0) & (ov == 1) & (e == 1)).sum())
+        tot["oracle_lost"] += int(((gv == 1) & (ov == 0) & (e == 1)).sum())
+        tot["unexplained"] += int((e == 0).sum())
     return tot
 
 

@@ -194,6 +194,8 @@ def test_atrium_frames_with_per_frame_rebuild_match_oracle_ray_by_ray(sponza, pr
         # lie beyond the running closest t although a triangle inside computes a smaller one: `neither` -- but the GPU's f32
         # slab parameters on outward-rounded boxes lose fewer than the reference's half ones)
         assert j["neither"] <= 2 + 0.01 * j["disputed"] and j["gpu_lost"] <= max(8, j["oracle_lost"]), f"frame {f}: {sorted(j.items())}"
+        js = replay.adjudicate_shadow(c, probe_o)  # the same for the shadow rays: a blocked ray reported free is a lost blocker
+        assert js["unexplained"] == 0 and js["gpu_lost"] <= max(8, js["oracle_lost"]), f"frame {f}: {sorted(js.items())}"
         assert_planes_ray_by_ray(r, o, c, prec, kept_l2=1e-4, kept_px=1e-2, max_outliers=0)
         for name in RADIANCE:
             lim = min(ATRIUM_F16_CEILING[name], TOL[prec]) if name in ("COLOR_INPROGRESS", "OUTPUT") else ATRIUM_F16_CEILING[name]
