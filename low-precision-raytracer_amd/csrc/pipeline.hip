@@ -595,8 +595,16 @@ LPRT_VAR_BEGIN
 template <typename T, bool FIRST, bool COMPOSE, bool COUNT, bool WIDE>
 __global__ void __launch_bounds__(256, AnyhitWaves<T>::value) k_trace_di(SceneDev<T> sc, FrameDev<T> fb0, ComposeArgs ca, Counters *counters) {
     const FrameDev<T> fb = at_sample(fb0, blockIdx.z);
-    const uint32_t p = tile_pixel(fb);
+    uint32_t p = tile_pixel(fb);
     const uint32_t npix = fb.win.npix();
+    if (!FIRST) {
+        // Only pixels whose GI ray hit something cast shadow rays in round 1 (41 % of the Cornell frame): the tile's pixels with
+        // rays first, so that they share waves and the waves without work leave at once (as k_trace_gi does by octant).
+        // Half precision 0.36 -> 0.33 ms, single 0.39 -> 0.37; ordering round 0 too, or either round by the number of
+        // light slots, costs more in scattered pixels than the fuller waves return (atrium round 0: 3.17 -> 3.36 ms).
+        const uint32_t key = (p < npix && fb.lc_mask[p]) ? 0u : 1u;
+        p = tile_pixel_of(fb, block_sort_order(key, 2u));
+    }
     Cnt<COUNT> cnt;
     if (p < npix) {
         const T zero = (T)0, one = (T)1;
