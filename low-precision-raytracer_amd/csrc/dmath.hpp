@@ -28,6 +28,7 @@ template <> struct Num<float> {
     static LPRT_DEV bool finite(float a) { return __builtin_isfinite(a); }
     static LPRT_DEV bool isnan(float a) { return a != a; }
     static LPRT_DEV float inf() { return __builtin_inff(); }
+    static LPRT_DEV float nan() { return __builtin_nanf(""); }
 };
 template <> struct Num<h16> {
     static constexpr bool is_half = true;
@@ -39,6 +40,7 @@ template <> struct Num<h16> {
     static LPRT_DEV bool finite(h16 a) { return __builtin_isfinite((float)a); }
     static LPRT_DEV bool isnan(h16 a) { return a != a; }
     static LPRT_DEV h16 inf() { return (h16)__builtin_inff(); }
+    static LPRT_DEV h16 nan() { return (h16)__builtin_nanf(""); }
 };
 
 template <typename T> LPRT_DEV T cvt(float v) { return Num<T>::from_f(v); }

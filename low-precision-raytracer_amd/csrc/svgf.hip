@@ -328,6 +328,12 @@ constexpr int WV_BX = 64;
 #ifndef LPRT_WV_FAST32
 #define LPRT_WV_FAST32 0 // the one-test taps and the flat-normal skip in single precision: measured slower, see below
 #endif
+#ifndef LPRT_WV_FLAT32
+#define LPRT_WV_FLAT32 0 // the flat-normal skip in single precision (interpolated normals of a flat wall rarely agree to the bit there)
+#endif
+#ifndef LPRT_WV_EAGER
+#define LPRT_WV_EAGER 0 // both lobes' colours requested with the tap's normal / depth / illumination instead of after the weight test
+#endif
 #ifndef LPRT_WV_BY32
 #define LPRT_WV_BY32 8
 #endif
@@ -349,7 +355,7 @@ __global__ void __launch_bounds__(WV_BX * WvRows<T>::value) k_wavelet(FrameDev<T
     constexpr bool LDS_COLOR = sizeof(T) == 2 || STRIDE < LPRT_WV_LDS_BELOW;
     __shared__ V4<T> s_nd[TH][TW], s_c0[LDS_COLOR ? TH : 1][LDS_COLOR ? TW : 1], s_c1[LDS_COLOR ? TH : 1][LDS_COLOR ? TW : 1];
     __shared__ V2<T> s_il[TH][TW];
-    __shared__ uint32_t s_nonfinite; // some staged colour / variance is inf or NaN: the taps must test every sample
+    __shared__ uint32_t s_bad[WV_BY]; // per wave: some colour / variance it staged is inf or NaN (then the taps test every sample)
     const int W = (int)fb.win.W, R = (int)fb.win.rows();
     const int tx = (int)(threadIdx.x % WV_BX), ty = (int)(threadIdx.x / WV_BX);
     const int oy = (int)(blockIdx.y % STRIDE), by = (int)(blockIdx.y / STRIDE);
@@ -357,43 +363,83 @@ __global__ void __launch_bounds__(WV_BX * WvRows<T>::value) k_wavelet(FrameDev<T
     // lat0 / row_hi: the rows this launch has to produce start at lattice row lat0 of every phase and end before window row
     // row_hi (launch_wavelet: a rank's strip needs level l only within the reach of the levels after it)
     const int r0 = lat0 + WV_BY * by - 2;                 // lattice row of tile row 0
-    // in single precision the one-test form measured 2 % slower than the tested one (0.649 vs 0.633 ms): half only
     constexpr bool FAST = LDS_COLOR && (sizeof(T) == 2 || LPRT_WV_FAST32);
-    if (FAST) {
-        if (threadIdx.x == 0)
-            s_nonfinite = 0u;
-        __syncthreads();
+    const T zero = (T)0;
+    // ---- every global read of the workgroup is requested before the first one is waited for: the thread's own 3 x 3 variances
+    // and depth gradient, then its share of the tile (2-4 texels).  Requested where they are used -- tile loop, barrier, sigma --
+    // they were three dependent round trips to memory per workgroup, and the three workgroups of a CU take them in step.
+    // Addresses outside the window are clamped into it (the value is dropped), so nothing here branches.
+    const int px = (int)blockIdx.x * WV_BX + tx, py = oy + STRIDE * (lat0 + WV_BY * by + ty);
+    const bool mine = px < W && py < row_hi;
+    const int pxc = px < W ? px : W - 1, pyc = py < R ? py : R - 1;
+    const uint32_t p = (uint32_t)(pyc * W + pxc);
+    T pv0[9], pv1[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) { // k = 3 (i + 1) + (j + 1): x outer, y inner
+        const int qx = pxc + k / 3 - 1, qy = pyc + k % 3 - 1;
+        const uint32_t q = (uint32_t)((qy < 0 ? 0 : qy >= R ? R - 1 : qy) * W + (qx < 0 ? 0 : qx >= W ? W - 1 : qx));
+        pv0[k] = vin0[q];
+        pv1[k] = vin1[q];
     }
-    bool bad = false;
-    for (int e = (int)threadIdx.x; e < TW * TH; e += WV_THREADS) {
+    const V2<T> grad = fb.depth_gradient[p];
+    constexpr int NIT = (TW * TH + WV_THREADS - 1) / WV_THREADS;
+    V4<T> r_nd[NIT], r_c0[LDS_COLOR ? NIT : 1], r_c1[LDS_COLOR ? NIT : 1];
+    V2<T> r_il[NIT];
+    bool r_in[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        // (threads past the tile's end in the last round all take its last texel, and all write it: no branch around the round)
+        const int e = min((int)threadIdx.x + it * WV_THREADS, TW * TH - 1);
         const int lx = e % TW, ly = e / TW;
         const int gx = x0 + lx, gy = oy + STRIDE * (r0 + ly);
-        if (gx >= 0 && gx < W && gy >= 0 && gy < R) {
-            const uint32_t q = (uint32_t)(gy * W + gx);
-            s_nd[ly][lx] = fb.g_normal_depth[q];
-            if (LDS_COLOR) {
-                const V4<T> c0 = in0[q], c1 = in1[q];
-                s_c0[ly][lx] = c0;
-                s_c1[ly][lx] = c1;
-                if (FAST)
-                    bad = bad || !(tfinite(c0.x) && tfinite(c0.y) && tfinite(c0.z) && tfinite(c0.w) && tfinite(c1.x) && tfinite(c1.y) &&
-                                   tfinite(c1.z) && tfinite(c1.w));
-            }
-            s_il[ly][lx] = V2<T>{fb.lobe[0].illum[q], fb.lobe[1].illum[q]};
+        r_in[it] = gx >= 0 && gx < W && gy >= 0 && gy < R;
+        const uint32_t q = (uint32_t)((gy < 0 ? 0 : gy >= R ? R - 1 : gy) * W + (gx < 0 ? 0 : gx >= W ? W - 1 : gx));
+        r_nd[it] = fb.g_normal_depth[q];
+        if (LDS_COLOR) {
+            r_c0[it] = in0[q];
+            r_c1[it] = in1[q];
         }
+        r_il[it] = V2<T>{fb.lobe[0].illum[q], fb.lobe[1].illum[q]};
     }
-    if (FAST && __builtin_amdgcn_ballot_w64(bad) && (threadIdx.x & 63) == 0)
-        atomicOr(&s_nonfinite, 1u);
+    bool bad = false;
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int e = min((int)threadIdx.x + it * WV_THREADS, TW * TH - 1);
+        const int lx = e % TW, ly = e / TW;
+        s_nd[ly][lx] = r_nd[it];
+        if (LDS_COLOR) {
+            const V4<T> c0 = r_c0[it], c1 = r_c1[it];
+            s_c0[ly][lx] = c0;
+            s_c1[ly][lx] = c1;
+            if (FAST)
+                bad = bad || (r_in[it] && !(tfinite(c0.x) && tfinite(c0.y) && tfinite(c0.z) && tfinite(c0.w) && tfinite(c1.x) && tfinite(c1.y) &&
+                                            tfinite(c1.z) && tfinite(c1.w)));
+        }
+        // a tap outside the window is skipped (cuda.hpp:1375-1380).  Here it carries a NaN illumination: its luminance weight, and
+        // with it h * w of both lobes, is NaN, and the test every tap makes anyway (`isfinite(h * w)`) drops it -- the 25 x 2
+        // bounds tests per pixel leave the tap loop
+        s_il[ly][lx] = r_in[it] ? r_il[it] : V2<T>{Num<T>::nan(), Num<T>::nan()};
+    }
+    // every lane stores its wave's flag (one word, one value per wave).  [The same store from lane 0 alone, behind a branch, made
+    // workgroups with non-finite samples take the one-test path on MI355X -- ISA identical but for the store's lane mask; the
+    // `svgf_always_test` A/B test and tools/gpu_ab_hash.sh catch it.]
+    const bool wave_bad = __builtin_amdgcn_ballot_w64(bad) != 0;
+    if (FAST)
+        s_bad[threadIdx.x >> 6] = wave_bad ? 1u : 0u;
     __syncthreads();
     // workgroup-uniform: with every staged sample finite, a tap needs one test (its own weight) instead of six, both
     // weight sums coincide and colour + variance accumulate as two packed pairs
-    const bool all_finite = FAST && !always_test && s_nonfinite == 0u;
-    const int px = (int)blockIdx.x * WV_BX + tx, py = oy + STRIDE * (lat0 + WV_BY * by + ty);
-    if (px >= W || py >= row_hi)
+    bool all_finite = FAST && !always_test;
+    if (FAST) {
+        uint32_t any_bad = 0u;
+#pragma unroll
+        for (int w = 0; w < WV_BY; w++)
+            any_bad |= s_bad[w];
+        all_finite = all_finite && any_bad == 0u;
+    }
+    if (!mine)
         return;
-    const uint32_t p = (uint32_t)(py * W + px);
     const int cx = tx + 2 * STRIDE, cy = ty + 2; // tile coordinates of the centre
-    const T zero = (T)0;
     const T hk[3] = {cvt<T>(0.375f), cvt<T>(0.25f), cvt<T>(0.0625f)};
     const T gk[2] = {cvt<T>(0.5f), cvt<T>(0.25f)};
     const V4<T> *in[2] = {in0, in1};
@@ -401,18 +447,19 @@ __global__ void __launch_bounds__(WV_BX * WvRows<T>::value) k_wavelet(FrameDev<T
     // 1. 3x3 gaussian of the variance (image neighbours, not lattice neighbours) -> sigma_l
     T sg[2] = {zero, zero};
     T gw = zero;
+#pragma unroll
     for (int i = -1; i <= 1; i++) {
         int qx = px + i;
         if (qx < 0 || qx >= W)
             continue;
+#pragma unroll
         for (int j = -1; j <= 1; j++) {
             int qy = py + j;
             if (qy < 0 || qy >= R)
                 continue;
             T g = gk[i < 0 ? -i : i] * gk[j < 0 ? -j : j];
-            uint32_t q = (uint32_t)(qy * W + qx);
-            sg[0] = fmadd(g, vin0[q], sg[0]);
-            sg[1] = fmadd(g, vin1[q], sg[1]);
+            sg[0] = fmadd(g, pv0[3 * (i + 1) + (j + 1)], sg[0]);
+            sg[1] = fmadd(g, pv1[3 * (i + 1) + (j + 1)], sg[1]);
             gw = gw + g;
         }
     }
@@ -425,11 +472,14 @@ __global__ void __launch_bounds__(WV_BX * WvRows<T>::value) k_wavelet(FrameDev<T
     const float k_l[2] = {__builtin_amdgcn_rcpf(den_l[0]) * 1.44269504088896340736f, __builtin_amdgcn_rcpf(den_l[1]) * 1.44269504088896340736f};
 #endif
     // 2. 5x5 a-trous taps, x outer / y inner as in the reference
+    // every tap of the thread at a constant offset from one LDS address
+    const int t0 = ty * TW + tx;
+    const V4<T> *t_nd = &s_nd[0][0] + t0, *t_c0 = &s_c0[0][0] + (LDS_COLOR ? t0 : 0), *t_c1 = &s_c1[0][0] + (LDS_COLOR ? t0 : 0);
+    const V2<T> *t_il = &s_il[0][0] + t0;
     const V4<T> nd_p = s_nd[cy][cx];
     // (half only: in single precision the skip measured 3 % slower, 0.650 vs 0.628 ms -- that kernel is not bound by its VALU count)
-    const bool FLAT = (sizeof(T) == 2 || LPRT_WV_FAST32) && !always_test;
+    const bool FLAT = (sizeof(T) == 2 || LPRT_WV_FLAT32) && !always_test;
     const T w_nn = normal_weight(xyz(nd_p), xyz(nd_p));
-    const V2<T> grad = fb.depth_gradient[p];
     const V2<T> il_p = s_il[cy][cx];
     const T illum_p[2] = {il_p.x, il_p.y};
     T nvar[2] = {zero, zero}, wv[2] = {zero, zero}, wc[2] = {zero, zero};
@@ -440,22 +490,18 @@ __global__ void __launch_bounds__(WV_BX * WvRows<T>::value) k_wavelet(FrameDev<T
         T wsum[2] = {zero, zero};
 #pragma unroll
         for (int i = -2; i <= 2; i++) {
-            int qx = px + STRIDE * i;
-            if (qx < 0 || qx >= W)
-                continue;
 #pragma unroll
             for (int j = -2; j <= 2; j++) {
-                int qy = py + STRIDE * j;
-                if (qy < 0 || qy >= R)
-                    continue;
-                const int lx = cx + STRIDE * i, ly = cy + j;
+                const int tq = (j + 2) * TW + (i + 2) * STRIDE; // the tap, relative to the thread's top-left one
                 T h = hk[i < 0 ? -i : i] * hk[j < 0 ? -j : j];
-                const V4<T> nd_q = s_nd[ly][lx];
+                const V4<T> nd_q = t_nd[tq];
                 T w_z, w_n;
                 geo_weights(nd_p.w, nd_q.w, grad, cvt<T>((float)(STRIDE * i)), cvt<T>((float)(STRIDE * j)), xyz(nd_p), xyz(nd_q), w_z, w_n, w_nn, FLAT);
                 T wzn = w_z * w_n;
-                const V2<T> il_q = s_il[ly][lx];
+                const V2<T> il_q = t_il[tq];
                 const T iq[2] = {il_q.x, il_q.y};
+                constexpr bool EAGER = LDS_COLOR && LPRT_WV_EAGER;
+                const V4<T> cq_e[2] = {t_c0[EAGER ? tq : 0], t_c1[EAGER ? tq : 0]};
 #pragma unroll
                 for (int l = 0; l < 2; l++) {
                     float num = -(float)tabs(illum_p[l] - iq[l]);
@@ -466,10 +512,18 @@ __global__ void __launch_bounds__(WV_BX * WvRows<T>::value) k_wavelet(FrameDev<T
 #endif
                     T hw = h * (wzn * w_l);
                     if (tfinite(hw)) {
-                        const PackedV4<T> cq = __builtin_bit_cast(PackedV4<T>, l == 0 ? s_c0[LDS_COLOR ? ly : 0][LDS_COLOR ? lx : 0] : s_c1[LDS_COLOR ? ly : 0][LDS_COLOR ? lx : 0]);
-                        const v2 hh = {hw, hw}, hq = {hw, hw * hw};
-                        acc_xy[l] = acc_xy[l] + hh * cq.xy;
-                        acc_zw[l] = acc_zw[l] + hq * cq.zw; // hw * z | (hw * hw) * variance
+                        if (sizeof(T) == 4) {
+                            // single precision: scalar statements, which the compiler pairs into v_pk_fma_f32 itself; the explicit
+                            // pairs below cost it nine register copies per tap around the branch
+                            const V4<T> cq = EAGER ? cq_e[l] : (l == 0 ? t_c0 : t_c1)[LDS_COLOR ? tq : 0];
+                            nvar[l] = fmadd(hw * hw, cq.w, nvar[l]);
+                            ncol[l] = mk3(fmadd(hw, cq.x, ncol[l].x), fmadd(hw, cq.y, ncol[l].y), fmadd(hw, cq.z, ncol[l].z));
+                        } else {
+                            const PackedV4<T> cq = __builtin_bit_cast(PackedV4<T>, EAGER ? cq_e[l] : (l == 0 ? t_c0 : t_c1)[LDS_COLOR ? tq : 0]);
+                            const v2 hh = {hw, hw}, hq = {hw, hw * hw};
+                            acc_xy[l] = acc_xy[l] + hh * cq.xy;
+                            acc_zw[l] = acc_zw[l] + hq * cq.zw; // hw * z | (hw * hw) * variance
+                        }
                         wsum[l] = wsum[l] + hw;
                     }
                 }
@@ -477,29 +531,27 @@ __global__ void __launch_bounds__(WV_BX * WvRows<T>::value) k_wavelet(FrameDev<T
         }
 #pragma unroll
         for (int l = 0; l < 2; l++) {
-            ncol[l] = mk3((T)acc_xy[l].x, (T)acc_xy[l].y, (T)acc_zw[l].x);
-            nvar[l] = (T)acc_zw[l].y;
+            if (sizeof(T) == 2) {
+                ncol[l] = mk3((T)acc_xy[l].x, (T)acc_xy[l].y, (T)acc_zw[l].x);
+                nvar[l] = (T)acc_zw[l].y;
+            }
             wv[l] = wc[l] = wsum[l];
         }
     } else {
 #pragma unroll
         for (int i = -2; i <= 2; i++) {
-            int qx = px + STRIDE * i;
-            if (qx < 0 || qx >= W)
-                continue;
 #pragma unroll
             for (int j = -2; j <= 2; j++) {
-                int qy = py + STRIDE * j;
-                if (qy < 0 || qy >= R)
-                    continue;
-                const int lx = cx + STRIDE * i, ly = cy + j;
+                const int tq = (j + 2) * TW + (i + 2) * STRIDE; // the tap, relative to the thread's top-left one
                 T h = hk[i < 0 ? -i : i] * hk[j < 0 ? -j : j];
-                const V4<T> nd_q = s_nd[ly][lx];
+                const V4<T> nd_q = t_nd[tq];
                 T w_z, w_n;
                 geo_weights(nd_p.w, nd_q.w, grad, cvt<T>((float)(STRIDE * i)), cvt<T>((float)(STRIDE * j)), xyz(nd_p), xyz(nd_q), w_z, w_n, w_nn, FLAT);
                 T wzn = w_z * w_n;
-                const V2<T> il_q = s_il[ly][lx];
+                const V2<T> il_q = t_il[tq];
                 const T iq[2] = {il_q.x, il_q.y};
+                constexpr bool EAGER = LDS_COLOR && LPRT_WV_EAGER;
+                const V4<T> cq_e[2] = {t_c0[EAGER ? tq : 0], t_c1[EAGER ? tq : 0]};
 #pragma unroll
                 for (int l = 0; l < 2; l++) {
                     float num = -(float)tabs(illum_p[l] - iq[l]);
@@ -510,7 +562,7 @@ __global__ void __launch_bounds__(WV_BX * WvRows<T>::value) k_wavelet(FrameDev<T
 #endif
                     T hw = h * (wzn * w_l);
                     if (tfinite(hw)) {
-                        const V4<T> cq = LDS_COLOR ? (l == 0 ? s_c0[ly][lx] : s_c1[ly][lx]) : in[l][(uint32_t)(qy * W + qx)];
+                        const V4<T> cq = EAGER ? cq_e[l] : LDS_COLOR ? (l == 0 ? t_c0 : t_c1)[tq] : in[l][(uint32_t)((int)p + STRIDE * (j * W + i))];
                         if (tfinite(cq.w)) {
                             nvar[l] = fmadd(hw * hw, cq.w, nvar[l]);
                             wv[l] = wv[l] + hw;
