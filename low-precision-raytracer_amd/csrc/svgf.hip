@@ -331,6 +331,9 @@ constexpr int WV_BX = 64;
 #ifndef LPRT_WV_FLAT32
 #define LPRT_WV_FLAT32 0 // the flat-normal skip in single precision (interpolated normals of a flat wall rarely agree to the bit there)
 #endif
+#ifndef LPRT_WV_XCD
+#define LPRT_WV_XCD 1
+#endif
 #ifndef LPRT_WV_EAGER
 #define LPRT_WV_EAGER 0 // both lobes' colours requested with the tap's normal / depth / illumination instead of after the weight test
 #endif
@@ -358,8 +361,21 @@ __global__ void __launch_bounds__(WV_BX * WvRows<T>::value) k_wavelet(FrameDev<T
     __shared__ uint32_t s_bad[WV_BY]; // per wave: some colour / variance it staged is inf or NaN (then the taps test every sample)
     const int W = (int)fb.win.W, R = (int)fb.win.rows();
     const int tx = (int)(threadIdx.x % WV_BX), ty = (int)(threadIdx.x / WV_BX);
+#if LPRT_WV_XCD
+    // Workgroup -> tile.  Workgroups go to the 8 XCDs round-robin in launch order and every XCD has an L2 of its own, so tiles that
+    // share halo rows and columns (a third to two thirds of what a tile reads) were fetched by different L2s.  Here the
+    // workgroups of one XCD take a contiguous run of the tile order (phase, then tile row, then tile column): a tile's
+    // neighbours are its XCD's previous workgroup and the one a tile row earlier.  The work per tile is uniform, so the runs end together.
+    const uint32_t gx = gridDim.x, n_wg = gx * gridDim.y, lin = blockIdx.y * gx + blockIdx.x;
+    const uint32_t xcd = lin & 7u, run = n_wg >> 3, extra = n_wg & 7u;
+    const uint32_t vlin = xcd * run + (xcd < extra ? xcd : extra) + (lin >> 3);
+    const uint32_t bx = vlin % gx, vy = vlin / gx, nby = gridDim.y / STRIDE;
+    const int oy = (int)(vy / nby), by = (int)(vy % nby);
+#else
+    const uint32_t bx = blockIdx.x;
     const int oy = (int)(blockIdx.y % STRIDE), by = (int)(blockIdx.y / STRIDE);
-    const int x0 = (int)blockIdx.x * WV_BX - 2 * STRIDE; // image x of tile column 0
+#endif
+    const int x0 = (int)bx * WV_BX - 2 * STRIDE; // image x of tile column 0
     // lat0 / row_hi: the rows this launch has to produce start at lattice row lat0 of every phase and end before window row
     // row_hi (launch_wavelet: a rank's strip needs level l only within the reach of the levels after it)
     const int r0 = lat0 + WV_BY * by - 2;                 // lattice row of tile row 0
@@ -369,7 +385,7 @@ __global__ void __launch_bounds__(WV_BX * WvRows<T>::value) k_wavelet(FrameDev<T
     // and depth gradient, then its share of the tile (2-4 texels).  Requested where they are used -- tile loop, barrier, sigma --
     // they were three dependent round trips to memory per workgroup, and the three workgroups of a CU take them in step.
     // Addresses outside the window are clamped into it (the value is dropped), so nothing here branches.
-    const int px = (int)blockIdx.x * WV_BX + tx, py = oy + STRIDE * (lat0 + WV_BY * by + ty);
+    const int px = (int)bx * WV_BX + tx, py = oy + STRIDE * (lat0 + WV_BY * by + ty);
     const bool mine = px < W && py < row_hi;
     const int pxc = px < W ? px : W - 1, pyc = py < R ? py : R - 1;
     const uint32_t p = (uint32_t)(pyc * W + pxc);
