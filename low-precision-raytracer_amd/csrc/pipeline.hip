@@ -61,9 +61,12 @@ template <typename T> LPRT_DEV uint32_t tile_pixel(const FrameDev<T> &fb) {
 // whose item this thread should process.  Items with equal keys end up in the same waves, so a wave walks rays that point
 // into the same octant (or start in the same part of the scene), and the items without work (key = n_bins - 1) gather in
 // the last waves, which then leave at once.  Per-pixel results do not depend on which thread computes them.
-LPRT_DEV uint32_t block_sort_order(uint32_t key, uint32_t n_bins) {
+// `payload` travels with the item: on return it is the payload of the item this thread got (what the thread already knows about
+// its own pixel -- a light mask, a validity flag -- need not be fetched again for the pixel it is handed)
+LPRT_DEV uint32_t block_sort_order(uint32_t key, uint32_t n_bins, uint32_t &payload) {
     __shared__ uint16_t s_cnt[16][4];
     __shared__ uint16_t s_order[256];
+    __shared__ uint8_t s_pay[256];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     uint32_t below_in_wave = 0;
     for (uint32_t b = 0; b < n_bins; b++) {
@@ -80,8 +83,14 @@ LPRT_DEV uint32_t block_sort_order(uint32_t key, uint32_t n_bins) {
             if (b < key || (b == key && w < wave))
                 base += s_cnt[b][w];
     s_order[base + below_in_wave] = (uint16_t)threadIdx.x;
+    s_pay[base + below_in_wave] = (uint8_t)payload;
     __syncthreads();
+    payload = s_pay[threadIdx.x];
     return s_order[threadIdx.x];
+}
+LPRT_DEV uint32_t block_sort_order(uint32_t key, uint32_t n_bins) {
+    uint32_t none = 0u;
+    return block_sort_order(key, n_bins, none);
 }
 // pixel of work item `item` (0..255) of this workgroup's 32x8 tile
 template <typename T> LPRT_DEV uint32_t tile_pixel_of(const FrameDev<T> &fb, uint32_t item) {
@@ -597,19 +606,23 @@ __global__ void __launch_bounds__(256, AnyhitWaves<T>::value) k_trace_di(SceneDe
     const FrameDev<T> fb = at_sample(fb0, blockIdx.z);
     uint32_t p = tile_pixel(fb);
     const uint32_t npix = fb.win.npix();
+    uint32_t sorted_mask = 0u;
     if (!FIRST) {
         // Only pixels whose GI ray hit something cast shadow rays in round 1 (41 % of the Cornell frame): the tile's pixels with
         // rays first, so that they share waves and the waves without work leave at once (as k_trace_gi does by octant).
         // Half precision 0.36 -> 0.33 ms, single 0.39 -> 0.37; ordering round 0 too, or either round by the number of
         // light slots, costs more in scattered pixels than the fuller waves return (atrium round 0: 3.17 -> 3.36 ms).
-        const uint32_t key = (p < npix && fb.lc_mask[p]) ? 0u : 1u;
-        p = tile_pixel_of(fb, block_sort_order(key, 2u));
+        // The light mask travels with the pixel: the thread that gets it starts the pixel's other reads at once instead of
+        // fetching the mask a second time first (one dependent round trip to memory less in front of the traversal).
+        sorted_mask = p < npix ? fb.lc_mask[p] : 0u;
+        const uint32_t key = sorted_mask ? 0u : 1u;
+        p = tile_pixel_of(fb, block_sort_order(key, 2u, sorted_mask));
     }
     Cnt<COUNT> cnt;
     if (p < npix) {
         const T zero = (T)0, one = (T)1;
         V4<T> *intensity = FIRST ? fb.intensity0 : fb.intensity1;
-        const uint32_t mask = fb.lc_mask[p];
+        const uint32_t mask = FIRST ? (uint32_t)fb.lc_mask[p] : sorted_mask;
         V4<T> cur = intensity[p];
         if (mask) {
             const V3<T> source = xyz(FIRST ? fb.g_position[p] : fb.sc_position[p]);
@@ -675,17 +688,22 @@ template <typename T, bool COUNT>
 __global__ void __launch_bounds__(256, ClosestWaves<T>::value) k_trace_gi(SceneDev<T> sc, FrameDev<T> fb0, Counters *counters) {
     const FrameDev<T> fb = at_sample(fb0, blockIdx.z);
     uint32_t p = tile_pixel(fb);
+    uint32_t sorted_valid = 0u;
     {
+        // flag and direction are requested together (a pixel without a GI ray reads 16 bytes it does not need) and the flag
+        // travels with the pixel: two dependent round trips to memory less in front of the traversal
         uint32_t key = 8u; // no GI ray
-        if (p < fb.win.npix() && fb.gi_valid[p]) {
+        if (p < fb.win.npix()) {
+            sorted_valid = fb.gi_valid[p];
             const V4<T> d = fb.gi_direction[p];
-            key = ((float)d.x < 0.f ? 1u : 0u) | ((float)d.y < 0.f ? 2u : 0u) | ((float)d.z < 0.f ? 4u : 0u);
+            if (sorted_valid)
+                key = ((float)d.x < 0.f ? 1u : 0u) | ((float)d.y < 0.f ? 2u : 0u) | ((float)d.z < 0.f ? 4u : 0u);
         }
-        p = tile_pixel_of(fb, block_sort_order(key, 9u));
+        p = tile_pixel_of(fb, block_sort_order(key, 9u, sorted_valid));
     }
     Cnt<COUNT> cnt;
     if (p < fb.win.npix()) {
-        const bool cast = fb.gi_valid[p] != 0;
+        const bool cast = sorted_valid != 0u;
         Isect<T> is;
         is.hit = false;
         if (cast) {
