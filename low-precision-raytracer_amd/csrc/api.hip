@@ -93,6 +93,7 @@ struct CtxBase {
     // behaviour knobs (lprt_option): initialised from the environment once, in lprt_create; never read from it afterwards
     int opts[LPRT_OPT_COUNT] = {-1, -1, 1, 0, -1, 1, 0, -1, 0, 12, 20, 0, (int)LPRT_MAX_SAMPLE_BATCH, 0, 1, 0, -1};
     bool reference_slab() const { return opts[LPRT_OPT_REFERENCE_SLAB] != 0; }
+    bool rng_all_runs = false;
     void options_from_environment() {
         if (const char *w = std::getenv("LPRT_WIDE_WALK"))
             opts[LPRT_OPT_WIDE_WALK] = w[0] == '1' ? 1 : 0;
@@ -108,6 +109,7 @@ struct CtxBase {
             opts[LPRT_OPT_BLAS_LOCAL] = std::string(l) == "0" ? 0 : 1;
         if (std::getenv("LPRT_DEBUG_SYNC"))
             opts[LPRT_OPT_DEBUG_SYNC] = 1;
+        rng_all_runs = std::getenv("LPRT_RNG_ALL_RUNS") != nullptr; // A/B: states for the runs of background pixels too (RngStore::generate)
         if (const char *r = std::getenv("LPRT_RAY_STREAM"))
             opts[LPRT_OPT_RAY_STREAM] = r[0] == '1' ? 1 : 0;
         if (const char *r = std::getenv("LPRT_SAMPLE_BATCH"))
@@ -524,8 +526,9 @@ template <typename T> struct Impl : CtxBase {
                 // one batch: seed A over the window, the B seeds over the sample rows (the same range when `whole`)
                 std::vector<uint64_t> all(seeds_a);
                 all.insert(all.end(), seeds_b.begin(), seeds_b.end());
+                // (the G-buffer of this frame is in place: runs of 64 pixels without a covered one get no states)
                 rng.generate(stream, all.data(), (uint32_t)all.size(), (uint32_t)seeds_a.size(), total_px, first_px, npix, s_first_px, s_npix,
-                             d_rng_planes.as<uint32_t>(), seed_d.data());
+                             d_rng_planes.as<uint32_t>(), seed_d.data(), rng_all_runs ? nullptr : fb.g_color);
             });
         }
         jitter_d = first ? 0u : seed_d[0];

@@ -115,8 +115,12 @@ struct RngStore {
     // xorwow states of curand_init(seed_i, n, 0) for global pixels n in [first, first + count) -> planes[i][5][count], d_out[i]
     void generate(hipStream_t st, const uint64_t *seeds, uint32_t n_seeds, uint32_t total_pixels, uint32_t first, uint32_t count, uint32_t *planes,
                   uint32_t *d_out);
+    // g_color (optional; honoured when the two ranges coincide): the window's G-buffer colour plane, pixel `first` at [0].  A run of
+    // 64 pixel indices without a covered pixel (alpha 0) in the range gets no states: nothing reads them (shading and the TAA
+    // jitter draw random numbers for covered pixels only), and a third of the Cornell frame is background.
     void generate(hipStream_t st, const uint64_t *seeds, uint32_t n_seeds, uint32_t n_head, uint32_t total_pixels, uint32_t first, uint32_t count,
-                  uint32_t first2, uint32_t count2, uint32_t *planes, uint32_t *d_out);
+                  uint32_t first2, uint32_t count2, uint32_t *planes, uint32_t *d_out, const uint32_t *g_color = nullptr);
+    DevBuf d_runs; // [0]: number of runs with a covered pixel, [1 ..]: their indices (relative to the range's first run), any order
 };
 
 } // namespace lprt

@@ -49,13 +49,22 @@ LPRT_DEV uint32_t xor_and(uint32_t acc, uint32_t col, uint32_t mask) { return __
 // small upper levels, whose few sources leave most lanes idle and whose cost is the LATENCY of one wave working through its
 // matrices one after the other -- three dependent launches of ~40 us each were a fixed 120 us per frame, 22 % of the frame
 // of a rank that renders an eighth of the image.
-template <int TOP, int JW>
+// LIST: the sources are the entries of `runs` (runs[0] of them, k_rng_live_runs) instead of 0 .. n_src - 1
+template <int TOP, int JW, bool LIST = false>
 __global__ void __launch_bounds__(256, 4) k_rng_expand(const XorMat *__restrict__ P, const uint32_t *__restrict__ src, TopBatch topb, TopVectors top1,
                                                        uint32_t n_src, uint32_t src_stride, uint32_t src_seed_stride, uint32_t *__restrict__ dst,
-                                                       uint32_t dst_first, uint32_t dst_count, uint32_t dst_stride, uint32_t dst_seed_stride) {
+                                                       uint32_t dst_first, uint32_t dst_count, uint32_t dst_stride, uint32_t dst_seed_stride,
+                                                       const uint32_t *__restrict__ runs = nullptr) {
     __shared__ uint4 mat[4][160 * 2]; // [wave][column][8 words]
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t sA = blockIdx.x * RNG_S + lane, sB = sA + 64;
+    uint32_t sA = blockIdx.x * RNG_S + lane, sB = sA + 64;
+    if (LIST) {
+        const uint32_t n_runs = runs[0];
+        if (blockIdx.x * RNG_S >= n_runs)
+            return; // (the grid is sized for every run of the range)
+        sA = sA < n_runs ? runs[1u + sA] : 0xffffffffu;
+        sB = sB < n_runs ? runs[1u + sB] : 0xffffffffu;
+    }
     const uint32_t jbase = blockIdx.y * (4 * JW);
     const uint32_t z = blockIdx.z;
     src += (size_t)z * src_seed_stride;
@@ -136,6 +145,34 @@ __global__ void __launch_bounds__(256, 4) k_rng_expand(const XorMat *__restrict_
                     dst[(size_t)k * dst_stride + (n - dst_first)] = half == 0 ? ra[k][jj] : rb[k][jj];
             }
         }
+    }
+}
+
+// runs[1 ..] = the runs r (64 pixel indices each, run 0 = global pixels 64 * s_begin ..) of [0, n_runs) that hold a covered pixel
+// of the range [first, first + count) (g_color: the range's plane, alpha != 0 = covered), runs[0] = their number (zeroed
+// before the launch).  One wave per run; a workgroup's 16 flags are appended with one atomic.
+__global__ void __launch_bounds__(1024) k_rng_live_runs(const uint32_t *__restrict__ g_color, uint32_t first, uint32_t count, uint32_t s_begin, uint32_t n_runs,
+                                                        uint32_t *__restrict__ runs) {
+    __shared__ uint32_t s_flag[16], s_base;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t r = blockIdx.x * 16u + wave, n = (s_begin + r) * 64u + lane;
+    const bool covered = r < n_runs && n >= first && n - first < count && (g_color[n - first] >> 24) != 0u;
+    const bool any = __builtin_amdgcn_ballot_w64(covered) != 0ull;
+    if (lane == 0)
+        s_flag[wave] = any ? 1u : 0u;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t c = 0;
+        for (int w = 0; w < 16; w++)
+            c += s_flag[w];
+        s_base = c ? atomicAdd(&runs[0], c) : 0u;
+    }
+    __syncthreads();
+    if (lane == 0 && any) {
+        uint32_t before = 0;
+        for (uint32_t w = 0; w < wave; w++)
+            before += s_flag[w];
+        runs[1u + s_base + before] = r;
     }
 }
 
@@ -245,7 +282,7 @@ void RngStore::generate(hipStream_t st, const uint64_t *seeds, uint32_t n_seeds,
 // upper expansion levels do not depend on the range and run once for all seeds; planes = the head seeds' planes
 // ([5][count] each), then the others' ([5][count2] each).
 void RngStore::generate(hipStream_t st, const uint64_t *seeds, uint32_t n_seeds, uint32_t n_head, uint32_t total_pixels, uint32_t first,
-                        uint32_t count, uint32_t first2, uint32_t count2, uint32_t *planes, uint32_t *d_out) {
+                        uint32_t count, uint32_t first2, uint32_t count2, uint32_t *planes, uint32_t *d_out, const uint32_t *g_color) {
     const Tables &t = tables();
     const uint32_t n1 = (total_pixels + 63) / 64, n2 = (n1 + 63) / 64, n3 = (n2 + 63) / 64;
     if (n3 > 64)
@@ -254,6 +291,16 @@ void RngStore::generate(hipStream_t st, const uint64_t *seeds, uint32_t n_seeds,
     const uint32_t w2_stride = n3 * 64, w1_stride = n2 * 64;
     if (first == first2 && count == count2)
         n_head = n_seeds; // one range: one last-level launch per batch
+    else
+        g_color = nullptr;
+    const uint32_t *runs = nullptr;
+    if (g_color && count != 0) {
+        const uint32_t s_begin = first / 64, n_runs = (first + count + 63) / 64 - s_begin;
+        d_runs.reserve(sizeof(uint32_t) * ((size_t)n_runs + 1));
+        LPRT_HIP(hipMemsetAsync(d_runs.ptr, 0, sizeof(uint32_t), st));
+        hipLaunchKernelGGL(k_rng_live_runs, dim3((n_runs + 15) / 16), dim3(1024), 0, st, g_color, first, count, s_begin, n_runs, d_runs.as<uint32_t>());
+        runs = d_runs.as<uint32_t>();
+    }
     uint32_t done = 0;
     while (done < n_seeds) {
         const uint32_t batch = n3 <= 16 ? std::min<uint32_t>(RNG_MAX_BATCH, n_seeds - done) : 1;
@@ -296,7 +343,10 @@ void RngStore::generate(hipStream_t st, const uint64_t *seeds, uint32_t n_seeds,
             // workgroups -- a strip's launch is a fraction of one and then costs the latency of a wave's serial matvecs
             const uint32_t bx = (s_end - s_begin + RNG_S - 1) / RNG_S, nz = z1 - z0;
             const uint32_t *srcp = d_w1.as<uint32_t>() + (size_t)(z0 - done) * 5 * w1_stride + s_begin;
-            if (bx * 4u * nz >= 768u)
+            if (runs && part == 0 && bx * 4u * nz >= 768u)
+                hipLaunchKernelGGL((k_rng_expand<0, 4, true>), dim3(bx, 4, nz), dim3(256), 0, st, mats, srcp, topb, top1, s_end - s_begin, w1_stride, 5 * w1_stride,
+                                   out, f - s_begin * 64, c, c, 5 * c, runs);
+            else if (bx * 4u * nz >= 768u)
                 hipLaunchKernelGGL((k_rng_expand<0, 4>), dim3(bx, 4, nz), dim3(256), 0, st, mats, srcp, topb, top1, s_end - s_begin, w1_stride, 5 * w1_stride, out,
                                    f - s_begin * 64, c, c, 5 * c);
             else if (bx * 8u * nz >= 768u)
