@@ -891,6 +891,31 @@ def test_untested_window_sums_of_the_temporal_filter_never_change_a_frame(scene_
         assert np.array_equal(a, b, equal_nan=True)
 
 
+@pytest.mark.parametrize("prec", [abi.F32, abi.F16])
+def test_random_states_of_background_runs_are_never_read(prec, monkeypatch):
+    """The last level of the RNG expansion skips the runs of 64 pixel indices without a covered pixel (rng.hip:
+    k_rng_live_runs): nothing may read those states.  With every run expanded (LPRT_RNG_ALL_RUNS, read when the context is
+    created) three moving Cornell frames -- a third of each is background -- must come out bit for bit the same, at a frame
+    width that is not a multiple of 64 (runs straddle rows)."""
+    cornell = scenes.cornell_box()
+    outs = []
+    for every_run in (False, True):
+        if every_run:
+            monkeypatch.setenv("LPRT_RNG_ALL_RUNS", "1")
+        else:
+            monkeypatch.delenv("LPRT_RNG_ALL_RUNS", raising=False)
+        r = lprt_amd.Renderer(333, 187, prec)
+        r.load_scene(cornell)
+        for k in range(3):
+            r.set_scene(scenes.moving_cornell(k, cornell))
+            r.render(abi.default_settings(spp=2))
+        outs.append(tuple(r.read(n) for n in ("OUTPUT", "COLOR_INPROGRESS", "INTENSITY0", "INTENSITY1", "RAW_GI_COLORED", "GI_DIRECTION")))
+        r.close()
+    assert (np.asarray(outs[0][0])[..., :3] == 0).all(axis=-1).mean() > 0.05  # (there IS background in these frames)
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b, equal_nan=True)
+
+
 @pytest.mark.parametrize("scene_name", ["cornell", "small_test"])
 def test_reusing_round0_shadow_rays_gives_the_same_frames(scene_name):
     """lprt_frame_settings.reuse_direct_light: the shadow rays of round 0 do not depend on the sample, so casting them for
