@@ -279,6 +279,9 @@ LPRT_DEV void geo_weights(T depth_p, T depth_q, V2<T> grad, T dx, T dy, V3<T> n_
         w_n = normal_weight(n_p, n_q);
 }
 
+#ifndef LPRT_WV_SKIP_EMPTY
+#define LPRT_WV_SKIP_EMPTY 1 // waves of pixels without a normal leave the weighted windows out (k_moments, k_wavelet)
+#endif
 // ---- temporal_accumulation_moments (cuda.hpp:1245-1337), both lobes ---------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256) k_moments(FrameDev<T> fb) {
@@ -296,7 +299,10 @@ __global__ void __launch_bounds__(256) k_moments(FrameDev<T> fb) {
         const V4<T> nd_p = fb.g_normal_depth[p];
         const V2<T> grad = fb.depth_gradient[p];
         T weight[2] = {zero, zero};
-        for (int i = -2; i <= 2; i++) {
+        // (a wave of pixels without a normal leaves the window out, as in k_wavelet: every h * w is +0 or NaN, the sums stay +0)
+        const bool no_normal = nd_p.x == zero && nd_p.y == zero && nd_p.z == zero;
+        const bool wave_has_taps = !LPRT_WV_SKIP_EMPTY || __builtin_amdgcn_ballot_w64(!no_normal) != 0ull;
+        for (int i = -2; wave_has_taps && i <= 2; i++) {
             int qx = px + i;
             if (qx < 0 || qx >= W)
                 continue;
@@ -523,7 +529,14 @@ __global__ void __launch_bounds__(WV_BX * WvRows<T>::value) k_wavelet(FrameDev<T
     const T illum_p[2] = {il_p.x, il_p.y};
     T nvar[2] = {zero, zero}, wv[2] = {zero, zero}, wc[2] = {zero, zero};
     V3<T> ncol[2] = {zero3<T>(), zero3<T>()};
-    if (all_finite) {
+    // A pixel whose normal is the zero vector -- every pixel no primary ray covered -- gives every tap the normal weight
+    // pow(max(0, 0 . n_q), 128) = +0 (or NaN, where n_q is not finite): h * w is +0 or NaN for all 25 taps, the sums stay at
+    // the +0 they start from and the pixel keeps its own colour and variance (the 0 / 0 below).  A wave of such pixels leaves the
+    // taps out and arrives at the same sums: a third of the Cornell frame is background.  (LPRT_WV_SKIP_EMPTY=0: never)
+    const bool no_normal = nd_p.x == zero && nd_p.y == zero && nd_p.z == zero;
+    const bool wave_has_taps = !LPRT_WV_SKIP_EMPTY || always_test || __builtin_amdgcn_ballot_w64(!no_normal) != 0ull;
+    if (!wave_has_taps) {
+    } else if (all_finite) {
         typedef typename PackedV4<T>::v2 v2;
         v2 acc_xy[2] = {{zero, zero}, {zero, zero}}, acc_zw[2] = {{zero, zero}, {zero, zero}}; // colour x y | colour z, variance
         T wsum[2] = {zero, zero};
