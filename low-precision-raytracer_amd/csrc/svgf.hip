@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256) k_temporal_color(FrameDev<T> fb, T color_
     if (threadIdx.x == 0)
         s_nonfinite = 0u;
     __syncthreads();
-    bool bad = false;
+    bool bad = false, nonzero = false;
     for (int e = (int)threadIdx.x; e < TC_TW * TC_TH; e += 256) {
         const int lx = e % TC_TW, ly = e / TC_TW;
         const int gx = x0 + lx, gy = y0 + ly;
@@ -119,17 +119,24 @@ __global__ void __launch_bounds__(256) k_temporal_color(FrameDev<T> fb, T color_
             tile[0][ly][lx] = c0;
             tile[1][ly][lx] = c1;
             bad = bad || !(tfinite(c0.x) && tfinite(c0.y) && tfinite(c0.z) && tfinite(c1.x) && tfinite(c1.y) && tfinite(c1.z));
+            nonzero = nonzero || !(c0.x == (T)0 && c0.y == (T)0 && c0.z == (T)0 && c1.x == (T)0 && c1.y == (T)0 && c1.z == (T)0);
         } else {
             // outside the frame: zeros, so that the untested window sums below can run over all 81 samples of every pixel (a sum
             // that starts at +0 is never -0, and x + (+0) == x for every other x: the zeros change no bit of it)
             tile[0][ly][lx] = tile[1][ly][lx] = V4<T>{(T)0, (T)0, (T)0, (T)0};
         }
     }
-    if (__builtin_amdgcn_ballot_w64(bad) && (threadIdx.x & 63) == 0)
-        atomicOr(&s_nonfinite, 1u);
+    {
+        const uint32_t flags = (__builtin_amdgcn_ballot_w64(bad) ? 1u : 0u) | (__builtin_amdgcn_ballot_w64(nonzero) ? 2u : 0u);
+        if (flags && (threadIdx.x & 63) == 0)
+            atomicOr(&s_nonfinite, flags);
+    }
     __syncthreads();
     // workgroup-uniform (LPRT_SVGF_ALWAYS_TEST=1 forces the per-sample tests for A/B runs)
-    const bool all_finite = s_nonfinite == 0u && !always_test;
+    const bool all_finite = (s_nonfinite & 1u) == 0u && !always_test;
+    // every staged colour is zero (a tile of background without a skybox): the window sums of +-0 are +0 whatever the count,
+    // the 81-sample loops are left out and the rest of the pass runs on those sums
+    const bool all_zero = (s_nonfinite & 2u) == 0u && !always_test;
     const int px = (int)blockIdx.x * TC_BX + tx, py = (int)blockIdx.y * TC_BY + ty;
     if (px >= W || py >= R)
         return;
@@ -140,7 +147,9 @@ __global__ void __launch_bounds__(256) k_temporal_color(FrameDev<T> fb, T color_
     for (int l = 0; l < 2; l++) {
         V3<T> pc = xyz(tile[l][ty + TC_R][tx + TC_R]);
         V3<T> m1 = zero3<T>(), m2 = zero3<T>(), wt = zero3<T>();
-        if (all_finite) {
+        if (all_zero) {
+            wt = mk3(one, one, one); // 0 / n = +0 for every count n >= 1
+        } else if (all_finite) {
             // every sample of the window counts: the same sums in the same order without the per-sample tests; the
             // sample count is a small integer, exact in either precision
             // two channels per instruction (v_pk_add/mul_f16, v_pk_add/mul_f32): each lane of a packed operation is an
