@@ -474,7 +474,8 @@ int lprt_get_option(lprt_ctx *ctx, lprt_option option, int *value);
  * (set = 1) expands random states for every pixel of the window.  The default expands none for the runs of 64 pixel indices that
  * hold no covered pixel of the frame's G-buffer: nothing reads them (rt/rtrt/cuda.hpp:1763-1764 initialises a state per
  * thread, but shade() and the TAA jitter draw numbers for covered pixels only), so frames do not depend on it
- * (tests/test_gpu_frame.py::test_random_states_of_background_runs_are_never_read). */
+ * (tests/test_gpu_frame.py::test_random_states_of_background_runs_are_never_read).  LPRT_RNG_BESIDE_BUILD=0: a frame with
+ * rebuild_blas expands its random states after the build instead of beside it on the context's second stream. */
 
 /* Sizes and counts of the LOADED library, for bindings that mirror this header in another language: a binding compares
  * them with its own mirror at load time, so that an out-array or struct of the wrong size is an error at start-up and

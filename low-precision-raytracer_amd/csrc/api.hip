@@ -66,6 +66,17 @@ struct CtxBase {
     lprt_precision precision = LPRT_F32;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // a second stream of the context's own for work that runs BESIDE the frame's stream between two events (sample_phase: the
+    // RNG expansion under the BLAS build); created on first use
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    void ensure_side_stream() {
+        if (side_stream)
+            return;
+        LPRT_HIP(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
+        LPRT_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        LPRT_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    }
     virtual ~CtxBase() {}
     virtual void upload_geometry(const lprt_vertex *, uint32_t, const uint32_t *, uint32_t, const lprt_mesh_vao *, uint32_t) = 0;
     virtual void upload_materials(const lprt_material *, uint32_t) = 0;
@@ -93,7 +104,7 @@ struct CtxBase {
     // behaviour knobs (lprt_option): initialised from the environment once, in lprt_create; never read from it afterwards
     int opts[LPRT_OPT_COUNT] = {-1, -1, 1, 0, -1, 1, 0, -1, 0, 12, 20, 0, (int)LPRT_MAX_SAMPLE_BATCH, 0, 1, 0, -1};
     bool reference_slab() const { return opts[LPRT_OPT_REFERENCE_SLAB] != 0; }
-    bool rng_all_runs = false;
+    bool rng_all_runs = false, rng_beside_build_on = true;
     void options_from_environment() {
         if (const char *w = std::getenv("LPRT_WIDE_WALK"))
             opts[LPRT_OPT_WIDE_WALK] = w[0] == '1' ? 1 : 0;
@@ -109,7 +120,9 @@ struct CtxBase {
             opts[LPRT_OPT_BLAS_LOCAL] = std::string(l) == "0" ? 0 : 1;
         if (std::getenv("LPRT_DEBUG_SYNC"))
             opts[LPRT_OPT_DEBUG_SYNC] = 1;
-        rng_all_runs = std::getenv("LPRT_RNG_ALL_RUNS") != nullptr; // A/B: states for the runs of background pixels too (RngStore::generate)
+        rng_all_runs = std::getenv("LPRT_RNG_ALL_RUNS") != nullptr;
+        if (const char *b = std::getenv("LPRT_RNG_BESIDE_BUILD"))
+            rng_beside_build_on = b[0] != '0'; // A/B: states for the runs of background pixels too (RngStore::generate)
         if (const char *r = std::getenv("LPRT_RAY_STREAM"))
             opts[LPRT_OPT_RAY_STREAM] = r[0] == '1' ? 1 : 0;
         if (const char *r = std::getenv("LPRT_SAMPLE_BATCH"))
@@ -482,12 +495,7 @@ template <typename T> struct Impl : CtxBase {
         // samples per launch of the per-sample stages (LPRT_OPT_SAMPLE_BATCH; FrameDev: sample slots)
         const uint32_t batch_max = std::min<uint32_t>({spp, (uint32_t)opts[LPRT_OPT_SAMPLE_BATCH], LPRT_MAX_SAMPLE_BATCH});
         ensure_sample_slots(batch_max);
-        if (fs.rebuild_blas) {
-            stage(LPRT_STAGE_BUILD_BLAS, [&] { geo.build_blas(stream, builder_kind(), opts[LPRT_OPT_BLAS_LOCAL] != 0); });
-            objrecs_dirty = true;
-            ensure_objrecs();
-        }
-        SceneDev<T> sc = frame_scene();
+        const bool first = frame_index == 0;
         const bool whole = sample_rows == 0 || (sample_first == win.row_begin && sample_rows == win.rows());
         FrameDev<T> sv = whole ? fb : rows_view(sample_first, sample_rows);
         const uint32_t total_px = win.W * win.H, first_px = win.row_begin * win.W, npix = win.npix();
@@ -497,18 +505,6 @@ template <typename T> struct Impl : CtxBase {
                 return fs.seeds[3 * s + (uint32_t)which];
             return 3 * (frame_index * spp + s) + 1 + (uint64_t)which;
         };
-        stage(LPRT_STAGE_PRIMARY, [&] { LPRT_TRACE(launch_fill_gbuffer)(stream, sc, fb, stage_counters(LPRT_STAGE_PRIMARY)); });
-        const bool first = frame_index == 0;
-        const bool wide_walk = wide_anyhit(), streams = ray_streams(), wide_closest = opts[LPRT_OPT_STREAM_WIDE_CLOSEST] != 0;
-        // round-0 shadow rays start on the camera-visible surface and aim at the same few lights: coherent, and the fused
-        // per-pixel kernel serves them better (atrium: 7.5 vs 12.2 ms per frame) unless streams are forced on
-        const bool stream_round0 = streams && opts[LPRT_OPT_RAY_STREAM] == 1;
-        if (streams) {
-            const size_t need = sizeof(uint32_t) * LPRT_STREAM_COUNTER_WORDS * (3 * (size_t)((spp + batch_max - 1) / batch_max) + 1);
-            d_stream_counters.reserve(need);
-            LPRT_HIP(hipMemsetAsync(d_stream_counters.ptr, 0, need, stream));
-            stream_launches = 0;
-        }
         // every curand_init of this frame: seed A of sample 0 (TAA jitter, frames >= 1) over the window + seed B of each
         // sample (shade #1 with GI) over the sample rows -- one batch when the two row ranges coincide.  shade #2 runs with
         // NO_GI and draws nothing (cuda.hpp:1900-1999).
@@ -520,17 +516,50 @@ template <typename T> struct Impl : CtxBase {
                 seeds_b.push_back(seed_of(s, 1));
         std::vector<uint32_t> seed_d(seeds_a.size() + seeds_b.size() + 1, 0u);
         const size_t b_planes_at = 5 * (size_t)npix * seeds_a.size();
-        if (!seeds_a.empty() || !seeds_b.empty()) {
+        const bool have_seeds = !seeds_a.empty() || !seeds_b.empty();
+        if (have_seeds)
             d_rng_planes.reserve(sizeof(uint32_t) * (b_planes_at + 5 * (size_t)s_npix * seeds_b.size()));
-            stage(LPRT_STAGE_RNG, [&] {
-                // one batch: seed A over the window, the B seeds over the sample rows (the same range when `whole`)
-                std::vector<uint64_t> all(seeds_a);
-                all.insert(all.end(), seeds_b.begin(), seeds_b.end());
-                // (the G-buffer of this frame is in place: runs of 64 pixels without a covered one get no states)
-                rng.generate(stream, all.data(), (uint32_t)all.size(), (uint32_t)seeds_a.size(), total_px, first_px, npix, s_first_px, s_npix,
-                             d_rng_planes.as<uint32_t>(), seed_d.data(), rng_all_runs ? nullptr : fb.g_color);
-            });
+        // one batch: seed A over the window, the B seeds over the sample rows (the same range when `whole`); g_color: the frame's
+        // G-buffer when it is in place -- runs of 64 pixels without a covered one get no states -- else null
+        auto expand_rng = [&](hipStream_t st, const uint32_t *g_color) {
+            std::vector<uint64_t> all(seeds_a);
+            all.insert(all.end(), seeds_b.begin(), seeds_b.end());
+            rng.generate(st, all.data(), (uint32_t)all.size(), (uint32_t)seeds_a.size(), total_px, first_px, npix, s_first_px, s_npix,
+                         d_rng_planes.as<uint32_t>(), seed_d.data(), g_color);
+        };
+        // A rebuilding frame starts with ~0.7 ms in which a few dozen workgroups work through the top levels of the surface-area
+        // build while the rest of the chip idles; the RNG expansion (pure vector instructions, 0.5 ms for the atrium's 9 seeds)
+        // needs nothing of the build and runs beside it on the context's second stream -- for every run of pixels: the G-buffer
+        // that tells the background runs apart is traced after the build -- and is joined in front of the first shading pass.
+        const bool rng_beside_build = have_seeds && fs.rebuild_blas && rng_beside_build_on && opts[LPRT_OPT_DEBUG_SYNC] == 0;
+        if (rng_beside_build) {
+            ensure_side_stream();
+            LPRT_HIP(hipEventRecord(ev_fork, stream)); // after everything that still reads last frame's states
+            LPRT_HIP(hipStreamWaitEvent(side_stream, ev_fork, 0));
+            expand_rng(side_stream, nullptr);
+            LPRT_HIP(hipEventRecord(ev_join, side_stream));
         }
+        if (fs.rebuild_blas) {
+            stage(LPRT_STAGE_BUILD_BLAS, [&] { geo.build_blas(stream, builder_kind(), opts[LPRT_OPT_BLAS_LOCAL] != 0); });
+            objrecs_dirty = true;
+            ensure_objrecs();
+        }
+        SceneDev<T> sc = frame_scene();
+        stage(LPRT_STAGE_PRIMARY, [&] { LPRT_TRACE(launch_fill_gbuffer)(stream, sc, fb, stage_counters(LPRT_STAGE_PRIMARY)); });
+        const bool wide_walk = wide_anyhit(), streams = ray_streams(), wide_closest = opts[LPRT_OPT_STREAM_WIDE_CLOSEST] != 0;
+        // round-0 shadow rays start on the camera-visible surface and aim at the same few lights: coherent, and the fused
+        // per-pixel kernel serves them better (atrium: 7.5 vs 12.2 ms per frame) unless streams are forced on
+        const bool stream_round0 = streams && opts[LPRT_OPT_RAY_STREAM] == 1;
+        if (streams) {
+            const size_t need = sizeof(uint32_t) * LPRT_STREAM_COUNTER_WORDS * (3 * (size_t)((spp + batch_max - 1) / batch_max) + 1);
+            d_stream_counters.reserve(need);
+            LPRT_HIP(hipMemsetAsync(d_stream_counters.ptr, 0, need, stream));
+            stream_launches = 0;
+        }
+        if (rng_beside_build)
+            LPRT_HIP(hipStreamWaitEvent(stream, ev_join, 0));
+        else if (have_seeds)
+            stage(LPRT_STAGE_RNG, [&] { expand_rng(stream, rng_all_runs ? nullptr : fb.g_color); });
         jitter_d = first ? 0u : seed_d[0];
         // opt-in: round 0's light commands and their visibility do not depend on the sample -> cast them for sample 0 only
         const bool reuse = fs.reuse_direct_light && fs.gi_on;
@@ -1147,6 +1176,11 @@ void lprt_destroy(lprt_ctx *ctx) {
         ctx->impl->timer.pending.clear();
         ctx->impl->timer.pool.clear();
         hipStream_t s = ctx->impl->own_stream ? ctx->impl->stream : nullptr;
+        if (ctx->impl->side_stream) {
+            (void)hipStreamDestroy(ctx->impl->side_stream);
+            (void)hipEventDestroy(ctx->impl->ev_fork);
+            (void)hipEventDestroy(ctx->impl->ev_join);
+        }
         ctx->impl.reset();
         if (s)
             (void)hipStreamDestroy(s);
