@@ -719,11 +719,70 @@ __device__ __forceinline__ float box_area(const float lo[3], const float hi[3]) 
 // one 1024-thread workgroup per node: up to 47 k triangles on the atrium).  Nodes above SAH_ONE_AXIS triangles bin the widest
 // axis of their domain only -- 7 LDS atomics per triangle instead of 21, on a few addresses all 16 waves fight over -- which
 // is where the plane of such a node lies anyway (tools/bvh_quality.cpp: +1 % box tests with EVERY node restricted so).
+// One triangle per lane into the bins of an axis (bin[k] = count, lo[3], hi[3] in order-preserving int space).  The triangles
+// of a node arrive in the order the level above left them in, so most lanes of a wave fall into the same one or two bins, and
+// 64 lanes adding to ONE LDS word are 64 atomics the LDS serves one after the other: level 0 of the atrium (24 workgroups of
+// 11 k triangles) spent 350 us on 77 k such atomics per workgroup.  Here the wave settles each bin it touches among itself
+// first -- the lanes of one bin are counted by a ballot and their boxes reduced by butterflies -- and ONE lane adds the result.
+#ifndef SAH_AGG_MIN
+#define SAH_AGG_MIN 16
+#endif
+__device__ __forceinline__ void sah_bin_add(int (*bins)[7], bool valid, uint32_t k, const float (&lo)[3], const float (&hi)[3]) {
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(valid);
+    // bins that hold a quarter of the wave or more are settled inside the wave (at most four rounds); whoever is left -- lanes
+    // spread over many bins, the rule below level 0, where a node's triangles are no longer in an order that follows the axis
+    // -- adds for itself: sixteen rounds of butterflies cost more than the atomics they replace (level 1: 111 -> 274 us)
+    while (todo) {
+        const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
+        const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)k, (int)leader);
+        const bool mine = valid && k == k0;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(mine) & todo;
+        if (__builtin_popcountll(m) < SAH_AGG_MIN)
+            break;
+        float mn[3], mx[3];
+#pragma unroll
+        for (int x = 0; x < 3; x++) {
+            mn[x] = mine ? lo[x] : 3.4e38f;
+            mx[x] = mine ? hi[x] : -3.4e38f;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+            for (int x = 0; x < 3; x++) {
+                mn[x] = fminf(mn[x], __shfl_xor(mn[x], off, 64));
+                mx[x] = fmaxf(mx[x], __shfl_xor(mx[x], off, 64));
+            }
+        if (lane == leader) {
+            int *bn = bins[k0];
+            atomicAdd(bn, (int)__builtin_popcountll(m));
+#pragma unroll
+            for (int x = 0; x < 3; x++) {
+                atomicMin(bn + 1 + x, f32_ordered(mn[x]));
+                atomicMax(bn + 4 + x, f32_ordered(mx[x]));
+            }
+        }
+        todo &= ~m;
+    }
+    if (valid && ((todo >> lane) & 1ull)) {
+        int *bn = bins[k];
+        atomicAdd(bn, 1);
+#pragma unroll
+        for (int x = 0; x < 3; x++) {
+            atomicMin(bn + 1 + x, f32_ordered(lo[x]));
+            atomicMax(bn + 4 + x, f32_ordered(hi[x]));
+        }
+    }
+}
+
 template <typename T, uint32_t GW>
 __global__ void __launch_bounds__(1024) k_sah_level(const BlasInfo *blas, uint32_t d, SahQueues q, const uint32_t *src, uint32_t *dst,
                                                                          uint32_t *fin, const float *tri_bounds, BlasNode<T> *inner, T *roots) {
     constexpr uint32_t NPB = GW == 1u ? 16u : 1u, GT = 64u * GW, KIND = GW == 1u ? 0u : 1u; // nodes per workgroup, threads per node
     __shared__ int s_bins[NPB][3][SAH_BINS][7]; // per node: count, lo[3], hi[3] (bounds in order-preserving int space)
+    // a big node's sixteen waves bin into copies of their own, merged afterwards: sixteen waves adding to the same sixteen
+    // LDS words queue up behind each other (the copies take level 0 of the atrium from 183 to 171 us)
+    __shared__ int s_wbins[GW > 1u ? GW : 1u][GW > 1u ? 3u : 1u][GW > 1u ? SAH_BINS : 1u][7];
     __shared__ int s_red[NPB][12];                 // group reductions (GW > 1)
     __shared__ uint32_t s_part[2][GW + 1u];        // per-wave left / right counts of a partition chunk (GW > 1)
     __shared__ uint32_t s_best[4];
@@ -760,6 +819,11 @@ __global__ void __launch_bounds__(1024) k_sah_level(const BlasInfo *blas, uint32
         const uint32_t f = qi % 7u;
         (&bins[0][0][0])[qi] = f == 0u ? 0 : (f < 4u ? 0x7fffffff : (int)0x80000000);
     }
+    if (GW > 1u)
+        for (uint32_t qi = t; qi < GW * 3u * SAH_BINS * 7u; qi += GT) {
+            const uint32_t f = qi % 7u;
+            (&s_wbins[0][0][0][0])[qi] = f == 0u ? 0 : (f < 4u ? 0x7fffffff : (int)0x80000000);
+        }
     float cmin[3], ext[3], scale[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -770,21 +834,96 @@ __global__ void __launch_bounds__(1024) k_sah_level(const BlasInfo *blas, uint32
     // the axis a big node bins: the widest of its domain (x on ties)
     const uint32_t wide_axis = (ext[1] > ext[0] && ext[1] > ext[2]) ? 1u : (ext[2] > ext[0] && ext[2] > ext[1]) ? 2u : 0u;
     sync(); // the bins are initialised
-    // pass 1: binning
-    for (uint32_t e = t; e < n; e += GT) {
-        const float *b = tri_bounds + 6 * (size_t)perm[e];
-        float lo[3] = {b[0], b[1], b[2]}, hi[3] = {b[3], b[4], b[5]};
+    // A node of at most UNR elements per thread keeps them in registers from here to the end of the partition (every node
+    // below level 1 of the atrium; a wave-per-node group always: SAH_BIG = 4 x 64): its index loads, then its box gathers, are
+    // in flight together ONCE.  Read where they are used, they were two dependent round trips to memory per 64 (or 1,024)
+    // triangles and pass -- sixteen in a row for a 256-triangle node -- with nothing else for the wave to do meanwhile.
+    constexpr uint32_t UNR = 4u;
+    // Big nodes only.  The wave-per-node groups of the lower levels come by the thousand: their round trips hide behind each
+    // other, and the registers this costs them (two 1,024-thread workgroups per CU need <= 64) cost more -- 60 -> 90 us a level.
+    const bool resident = GW > 1u && n <= UNR * GT;
+    constexpr bool KEEP_BOXES = true;
+    uint32_t rg[UNR];
+    float rb[UNR][6];
+    auto gather_boxes = [&]() {
+#pragma unroll
+        for (uint32_t u = 0; u < UNR; u++) {
+            const float *bp = tri_bounds + 6 * (size_t)(rg[u] != 0xffffffffu ? rg[u] : 0u);
+#pragma unroll
+            for (int x = 0; x < 6; x++)
+                rb[u][x] = bp[x];
+        }
+    };
+    if (resident) {
+#pragma unroll
+        for (uint32_t u = 0; u < UNR; u++)
+            rg[u] = t + u * GT < n ? perm[t + u * GT] : 0xffffffffu;
+        gather_boxes();
+    }
+    // one element into the bins: a wave-per-node group with plain atomics (its 64 lanes spread over the bins), a big node's
+    // waves into their own copies, settling crowded bins inside the wave first (sah_bin_add)
+    auto bin_one = [&](bool valid, const float (&bx)[6]) {
+        const float lo[3] = {bx[0], bx[1], bx[2]}, hi[3] = {bx[3], bx[4], bx[5]};
         for (uint32_t ai = 0; ai < n_axes; ai++) {
             const uint32_t a = n_axes == 3u ? ai : wide_axis;
             const float c = 0.5f * (lo[a] + hi[a]);
-            const uint32_t k = min((uint32_t)fmaxf((c - cmin[a]) * scale[a], 0.f), SAH_BINS - 1u);
-            int *bn = bins[ai][k];
-            atomicAdd(bn, 1);
+            const uint32_t k = valid ? min((uint32_t)fmaxf((c - cmin[a]) * scale[a], 0.f), SAH_BINS - 1u) : 0u;
+            if (GW > 1u) {
+                sah_bin_add(s_wbins[wv][ai], valid, k, lo, hi);
+            } else if (valid) {
+                int *bn = bins[ai][k];
+                atomicAdd(bn, 1);
 #pragma unroll
-            for (int x = 0; x < 3; x++) {
-                atomicMin(bn + 1 + x, f32_ordered(lo[x]));
-                atomicMax(bn + 4 + x, f32_ordered(hi[x]));
+                for (int x = 0; x < 3; x++) {
+                    atomicMin(bn + 1 + x, f32_ordered(lo[x]));
+                    atomicMax(bn + 4 + x, f32_ordered(hi[x]));
+                }
             }
+        }
+    };
+    // pass 1: binning
+    if (resident) {
+#pragma unroll
+        for (uint32_t u = 0; u < UNR; u++)
+            if (u * GT < n) // (uniform over the group: every lane of a wave goes through sah_bin_add)
+                bin_one(rg[u] != 0xffffffffu, rb[u]);
+    } else if (GW == 1u) {
+        for (uint32_t e = t; e < n; e += GT) {
+            const float *bp = tri_bounds + 6 * (size_t)perm[e];
+            const float bx[6] = {bp[0], bp[1], bp[2], bp[3], bp[4], bp[5]};
+            bin_one(true, bx);
+        }
+    } else {
+        // (a node this big is ONE workgroup walking 10^4 triangles: four elements per thread and round, their loads together)
+        for (uint32_t base = 0; base < n; base += UNR * GT) {
+            const uint32_t e0 = base + t;
+            uint32_t gi[UNR];
+            float bb[UNR][6];
+#pragma unroll
+            for (uint32_t u = 0; u < UNR; u++)
+                gi[u] = e0 + u * GT < n ? perm[e0 + u * GT] : 0xffffffffu;
+#pragma unroll
+            for (uint32_t u = 0; u < UNR; u++) {
+                const float *bp = tri_bounds + 6 * (size_t)(gi[u] != 0xffffffffu ? gi[u] : 0u);
+#pragma unroll
+                for (int x = 0; x < 6; x++)
+                    bb[u][x] = bp[x];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < UNR; u++)
+                bin_one(gi[u] != 0xffffffffu, bb[u]);
+        }
+    }
+    if (GW > 1u) { // the waves' copies into the node's bins
+        __syncthreads();
+        for (uint32_t qi = t; qi < 3u * SAH_BINS * 7u; qi += GT) {
+            const uint32_t f = qi % 7u;
+            int v = (&s_wbins[0][0][0][0])[qi];
+            for (uint32_t wq = 1; wq < GW; wq++) {
+                const int o = (&s_wbins[wq][0][0][0])[qi];
+                v = f == 0u ? v + o : (f < 4u ? min(v, o) : max(v, o));
+            }
+            (&bins[0][0][0])[qi] = v;
         }
     }
     sync();
@@ -859,14 +998,11 @@ __global__ void __launch_bounds__(1024) k_sah_level(const BlasInfo *blas, uint32
     uint32_t out_l = 0, out_r = 0;
     uint32_t *o1 = dst + bi.tri_base + l, *o2 = fin + bi.tri_base + l;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    for (uint32_t base = 0; base < n; base += GT) {
+    // one chunk of GT elements (element base + t of the node: triangle g with box b): ranks run on from chunk to chunk
+    auto rank_chunk = [&](uint32_t base, bool valid, uint32_t g, const float (&b)[6]) {
         const uint32_t e = base + t;
-        const bool valid = e < n;
-        uint32_t g = 0;
         bool left = false;
         if (valid) {
-            g = perm[e];
-            const float *b = tri_bounds + 6 * (size_t)g;
             if (by_plane) {
                 const float c = 0.5f * (b[axis] + b[3 + axis]);
                 left = min((uint32_t)fmaxf((c - cmin[axis]) * scale[axis], 0.f), SAH_BINS - 1u) <= plane;
@@ -907,6 +1043,58 @@ __global__ void __launch_bounds__(1024) k_sah_level(const BlasInfo *blas, uint32
         out_r += tot_r;
         if (GW > 1u)
             __syncthreads(); // s_part is rewritten by the next chunk
+    };
+    if (resident) {
+        if (!KEEP_BOXES)
+            gather_boxes();
+#pragma unroll
+        for (uint32_t u = 0; u < UNR; u++)
+            if (u * GT < n)
+                rank_chunk(u * GT, rg[u] != 0xffffffffu, rg[u], rb[u]);
+    } else if (GW == 1u) {
+        for (uint32_t base = 0; base < n; base += GT) {
+            const uint32_t e = base + t;
+            uint32_t g = 0;
+            float bx[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (e < n) {
+                g = perm[e];
+                const float *bp = tri_bounds + 6 * (size_t)g;
+#pragma unroll
+                for (int x = 0; x < 6; x++)
+                    bx[x] = bp[x];
+            }
+            rank_chunk(base, e < n, g, bx);
+        }
+    } else {
+        // the chunks are sequential, their loads need not be: while chunk c is ranked, the box of chunk c + 1's element and the
+        // index of chunk c + 2's are on their way
+        uint32_t g_cur = t < n ? perm[t] : 0u, g_nx1 = t + GT < n ? perm[t + GT] : 0u;
+        float b_cur[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (t < n) {
+            const float *bp = tri_bounds + 6 * (size_t)g_cur;
+#pragma unroll
+            for (int x = 0; x < 6; x++)
+                b_cur[x] = bp[x];
+        }
+        for (uint32_t base = 0; base < n; base += GT) {
+            const uint32_t e = base + t;
+            float b_nx1[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            uint32_t g_nx2 = 0u;
+            if (e + GT < n) {
+                const float *bp = tri_bounds + 6 * (size_t)g_nx1;
+#pragma unroll
+                for (int x = 0; x < 6; x++)
+                    b_nx1[x] = bp[x];
+            }
+            if (e + 2u * GT < n)
+                g_nx2 = perm[e + 2u * GT];
+            rank_chunk(base, e < n, g_cur, b_cur);
+            g_cur = g_nx1;
+            g_nx1 = g_nx2;
+#pragma unroll
+            for (int x = 0; x < 6; x++)
+                b_cur[x] = b_nx1[x];
+        }
     }
 #pragma unroll
     for (int sd = 0; sd < 2; sd++)
