@@ -916,6 +916,30 @@ def test_random_states_of_background_runs_are_never_read(prec, monkeypatch):
         assert np.array_equal(a, b, equal_nan=True)
 
 
+def test_random_states_expanded_beside_the_blas_build_are_the_same_states(monkeypatch):
+    """A frame that rebuilds its BLAS set expands its random states on the context's second stream, beside the build (api.hip:
+    sample_phase).  With the serial order (LPRT_RNG_BESIDE_BUILD=0, read when the context is created) four rebuilding frames of
+    the small test scene must come out bit for bit the same, pre-denoise planes included."""
+    sc = scenes.SCENES["small_test"]()
+    outs = []
+    for beside in (True, False):
+        if beside:
+            monkeypatch.delenv("LPRT_RNG_BESIDE_BUILD", raising=False)
+        else:
+            monkeypatch.setenv("LPRT_RNG_BESIDE_BUILD", "0")
+        r = lprt_amd.Renderer(320, 180, abi.F16)
+        r.load_scene(sc)
+        fs = abi.default_settings(spp=3)
+        fs.rebuild_blas = 1
+        for _ in range(4):
+            r.set_scene(sc)
+            r.render(fs)
+        outs.append(tuple(r.read(n) for n in ("OUTPUT", "COLOR_INPROGRESS", "INTENSITY0", "INTENSITY1", "RAW_GI_COLORED", "GI_DIRECTION")))
+        r.close()
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b, equal_nan=True)
+
+
 @pytest.mark.parametrize("scene_name", ["cornell", "small_test"])
 def test_reusing_round0_shadow_rays_gives_the_same_frames(scene_name):
     """lprt_frame_settings.reuse_direct_light: the shadow rays of round 0 do not depend on the sample, so casting them for
